@@ -1,0 +1,209 @@
+"""ctypes binding of libpgx.so (include/pgx.h). Thin on purpose: argument marshalling
+and error translation only. There is no CPU fallback -- if the library or a GPU is
+missing, the first compute call raises PgxError."""
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libpgx.so')
+
+
+class PgxError(RuntimeError):
+    pass
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [('name', C.c_char * 64), ('arch', C.c_char * 32), ('device_id', C.c_int32),
+                ('compute_units', C.c_int32), ('wavefront_size', C.c_int32),
+                ('lds_bytes_per_block', C.c_int32), ('hbm_bytes', C.c_uint64),
+                ('clock_khz', C.c_int32), ('reserved', C.c_int32)]
+
+
+class ClusterParams(C.Structure):
+    _fields_ = [('alphabet', C.c_int32), ('word_len', C.c_int32), ('band_width', C.c_int32),
+                ('min_length', C.c_int32), ('both_strands', C.c_int32), ('batch_size', C.c_int32),
+                ('identity', C.c_double), ('aan_cutoff', C.c_double), ('aas_cutoff', C.c_double),
+                ('reserved', C.c_int64 * 4)]
+
+
+STAT_FIELDS = ('n_input', 'n_clustered', 'n_clusters', 'sum_len_queries', 'sum_len_reps', 'rep_words',
+               'posting_visits', 'filter_pairs', 'aligned_pairs', 'aligned_rep_len', 'dp_cells', 'sweeps')
+
+
+class ClusterStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in STAT_FIELDS] + [('reserved', C.c_uint64 * 4)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in STAT_FIELDS}
+
+
+# every symbol include/pgx.h declares: (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    'pgx_version': (C.c_int, []),
+    'pgx_last_error': (C.c_char_p, []),
+    'pgx_ctx_create': (C.c_int, [C.c_int, C.POINTER(_P)]),
+    'pgx_ctx_destroy': (None, [_P]),
+    'pgx_device_info': (C.c_int, [_P, C.POINTER(DeviceInfo)]),
+    'pgx_profile_enable': (C.c_int, [_P, C.c_int]),
+    'pgx_profile_reset': (C.c_int, [_P]),
+    'pgx_profile_count': (C.c_int, [_P]),
+    'pgx_profile_read': (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_uint64)]),
+    'pgx_bitmap_stride_words': (C.c_uint32, [C.c_uint32]),
+    'pgx_presence_bitmap': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
+    'pgx_presence_bitmap_dev': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P]),
+    'pgx_pan_core': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, _P]),
+    'pgx_pan_core_workspace_bytes': (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    'pgx_pan_core_dev': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, _P, _P,
+                                   C.c_size_t, _P]),
+    'pgx_cluster_greedy': (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(ClusterParams), _P, _P, _P, _P,
+                                     C.POINTER(C.c_uint32), C.POINTER(ClusterStats)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libpgx.so once; raises PgxError if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB_PATH):
+                raise PgxError('%s not found: build it with `python -c "import __graft_entry__ as g; '
+                               'g.build()"` or `make -C pangenomix_amd/csrc` (there is no CPU fallback)'
+                               % _LIB_PATH)
+            handle = C.CDLL(_LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(handle, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PgxError('libpgx error %d: %s' % (rc, lib().pgx_last_error().decode('utf-8', 'replace')))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context(object):
+    """Owns a pgx_ctx (device state). One per thread; not re-entrant."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        check(lib().pgx_ctx_create(int(device_id), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().pgx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def device_info(self):
+        info = DeviceInfo()
+        check(lib().pgx_device_info(self._h, C.byref(info)))
+        return {'name': info.name.decode(), 'arch': info.arch.decode(), 'device_id': info.device_id,
+                'compute_units': info.compute_units, 'wavefront_size': info.wavefront_size,
+                'lds_bytes_per_block': info.lds_bytes_per_block, 'hbm_bytes': info.hbm_bytes,
+                'clock_khz': info.clock_khz}
+
+    # -- per-kernel timing ---------------------------------------------------
+    def profile(self, on=True):
+        check(lib().pgx_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(lib().pgx_profile_reset(self._h))
+
+    def profile_read(self):
+        """{kernel name: (total_ms, launches)}; waits for pending events."""
+        out = {}
+        for slot in range(lib().pgx_profile_count(self._h)):
+            name = C.create_string_buffer(64)
+            ms, n = C.c_double(0), C.c_uint64(0)
+            check(lib().pgx_profile_read(self._h, slot, name, 64, C.byref(ms), C.byref(n)))
+            out[name.value.decode()] = (ms.value, int(n.value))
+        return out
+
+    # -- device-resident variants (pointers are raw device addresses, e.g. torch data_ptr) --
+    def presence_bitmap_dev(self, d_rows, d_genomes, n_records, n_rows, n_genomes, d_bits, stream=0):
+        check(lib().pgx_presence_bitmap_dev(self._h, d_rows, d_genomes, int(n_records), int(n_rows),
+                                            int(n_genomes), d_bits, stream))
+
+    def pan_core_dev(self, d_bits, n_genes, n_genomes, d_perms, n_iter, d_pan, d_core, d_ws, ws_bytes, stream=0):
+        check(lib().pgx_pan_core_dev(self._h, d_bits, int(n_genes), int(n_genomes), d_perms, int(n_iter),
+                                     d_pan, d_core, d_ws, int(ws_bytes), stream))
+
+    # -- K3 ----------------------------------------------------------------
+    def presence_bitmap(self, rows, genomes, n_rows, n_genomes):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        genomes = np.ascontiguousarray(genomes, dtype=np.int32)
+        if rows.shape != genomes.shape or rows.ndim != 1:
+            raise ValueError('rows and genomes must be 1-D arrays of equal length')
+        stride = lib().pgx_bitmap_stride_words(int(n_rows))
+        bits = np.empty((int(n_genomes), stride), dtype=np.uint64)
+        check(lib().pgx_presence_bitmap(self._h, _ptr(rows), _ptr(genomes), rows.size,
+                                        int(n_rows), int(n_genomes), _ptr(bits)))
+        return bits
+
+    def pan_core(self, bits, n_genes, perms):
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        n_iter, n_genomes = perms.shape
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        stride = lib().pgx_bitmap_stride_words(int(n_genes))
+        if bits.shape != (n_genomes, stride):
+            raise ValueError('bitmap shape %r does not match (%d, %d)' % (bits.shape, n_genomes, stride))
+        pan = np.empty((n_iter, n_genomes), dtype=np.int32)
+        core = np.empty((n_iter, n_genomes), dtype=np.int32)
+        check(lib().pgx_pan_core(self._h, _ptr(bits), int(n_genes), int(n_genomes), _ptr(perms),
+                                 int(n_iter), _ptr(pan), _ptr(core)))
+        return pan, core
+
+    # -- K1/K2 ---------------------------------------------------------------
+    def cluster_greedy(self, residues, offsets, params):
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        out_cluster = np.empty(n, dtype=np.int32)
+        out_member = np.empty(n, dtype=np.int32)
+        out_identity = np.empty(n, dtype=np.float32)
+        out_strand = np.zeros(n, dtype=np.uint8)
+        n_clusters = C.c_uint32(0)
+        stats = ClusterStats()
+        check(lib().pgx_cluster_greedy(self._h, _ptr(residues), _ptr(offsets), n, C.byref(params),
+                                       _ptr(out_cluster), _ptr(out_member), _ptr(out_identity),
+                                       _ptr(out_strand), C.byref(n_clusters), C.byref(stats)))
+        return out_cluster, out_member, out_identity, out_strand, int(n_clusters.value), stats.as_dict()
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on device LOCAL_RANK (one process per GPU) or 0."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get('LOCAL_RANK', '0')))
+    return _default_ctx

@@ -1,0 +1,299 @@
+// K3: presence/absence bitmap + pan/core rarefaction curves on gfx950.
+//
+// Replaces the Python double loop of pangenome_analysis.py:81-90
+//     gene_incidence += gene_data[col,:]
+//     pan[i,j]  = (gene_incidence > 0).sum()
+//     core[i,j] = (gene_incidence == j+1).sum()
+// with, per iteration, a running OR / running AND over bit-packed genome rows taken in
+// permuted order and a popcount per step (exact because the matrix is 0/1).
+//
+// Data layout in HBM
+//   bits[genome][stride] uint64, gene g = bit (g&63) of word (g>>6); stride is a multiple
+//   of 16 words (128 B). A row is cut into 8 equal *stripes* of Ls 16-byte lanes; stripe x
+//   is only ever read by workgroups with blockIdx % 8 == x, i.e. (round-robin dispatch) by
+//   one XCD, so each XCD's private 4 MiB L2 holds 1/8 of the matrix and every re-read of a
+//   row (n_iter times) is an L2 hit instead of an Infinity-Cache / HBM access.
+//
+// Work decomposition
+//   item (iter, stripe, v): one wave walks all S steps of iteration `iter` over the lanes
+//   [v*Lw, (v+1)*Lw) of its stripe, one dwordx4 (128 genes) per lane per step, loads
+//   issued PC_UNROLL steps ahead. Per step the lane counts are packed (pan | core<<16),
+//   summed over the wave with 6 DPP adds, and the wave total is parked in lane (j & 63);
+//   every 64 steps the wave stores 64 totals with one coalesced store into
+//   partial[stripe*wps+v][iter][j]. A second, tiny kernel sums the 8*wps partials.
+//   No atomics, bit-reproducible.
+//
+// Roofline: HBM/L2 streaming. Algorithmic bytes per iteration = S*ceil(G/64)*8 + 2*S*4 (+S*4
+// for the permutation), SURVEY §8d.
+#include "pgx_internal.h"
+
+namespace {
+
+constexpr int PC_STRIPES = 8;  // XCDs per MI355X
+constexpr int PC_WAVES = 4;    // waves per workgroup
+constexpr int PC_UNROLL = 8;   // rows in flight per wave
+
+struct PanCoreGeom {
+    uint32_t words;     // ceil(G/64)
+    uint32_t stride;    // padded words per genome (multiple of 16)
+    uint32_t Ls;        // 16-byte lanes per stripe
+    uint32_t wps;       // waves per stripe
+    uint32_t Lw;        // lanes per wave
+    uint32_t partials;  // 8 * wps
+};
+
+PanCoreGeom make_geom(uint32_t n_genes) {
+    PanCoreGeom g;
+    g.words = (n_genes + 63) / 64;
+    g.stride = pgx_bitmap_stride_words(n_genes);
+    g.Ls = g.stride / 16;
+    const uint32_t w0 = (g.Ls + 63) / 64;
+    g.Lw = (g.Ls + w0 - 1) / w0;           // balanced lanes per wave, <= 64
+    g.wps = (g.Ls + g.Lw - 1) / g.Lw;      // so that (wps-1)*Lw < Ls: no empty wave
+    g.partials = PC_STRIPES * g.wps;
+    return g;
+}
+
+// Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic):
+// xor-1, xor-2 inside quads, half-row mirror, row mirror -> every lane holds its row-of-16
+// sum; row_bcast15 folds rows 0->1 and 2->3, row_bcast31 folds the lower half into rows 2,3;
+// lane 63 then holds the wave total.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);  // row_mirror
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);  // row_bcast15 -> rows 1,3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);  // row_bcast31 -> rows 2,3
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+__device__ __forceinline__ uint32_t popc128(const uint4 &v) {
+    return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+}
+
+__global__ __launch_bounds__(PC_WAVES * 64) void pan_core_sweep_kernel(
+    const uint4 *__restrict__ bits, uint32_t stride_bytes, const int32_t *__restrict__ perms,
+    uint32_t n_iter, uint32_t S, uint32_t Ls, uint32_t wps, uint32_t Lw,
+    uint32_t *__restrict__ partial) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stripe = blockIdx.x & (PC_STRIPES - 1);
+    const uint32_t item = __builtin_amdgcn_readfirstlane(
+        (blockIdx.x / PC_STRIPES) * PC_WAVES + (threadIdx.x >> 6));
+    if (item >= n_iter * wps) return;  // wave-uniform
+    const uint32_t iter = item / wps;
+    const uint32_t v = item - iter * wps;
+    const uint32_t lane0 = v * Lw;                // < Ls by construction of the geometry
+    const uint32_t nl = min(Lw, Ls - lane0);      // >= 1
+    const bool active = lane < nl;
+    // idle lanes re-read the wave's last live lane (always in bounds) and are masked out
+    // of the counts, so the load itself is unconditional and coalesced.
+    const uint32_t lane_off = (stripe * Ls + lane0 + (active ? lane : nl - 1u)) * 16u;
+    const char *bytes = reinterpret_cast<const char *>(bits);
+    const int32_t *prow = perms + (size_t)iter * S;
+    uint32_t *out = partial + ((size_t)(stripe * wps + v) * n_iter + iter) * S;
+
+    uint4 acc_or = make_uint4(0u, 0u, 0u, 0u);
+    uint4 acc_and = make_uint4(~0u, ~0u, ~0u, ~0u);
+    uint32_t parked = 0;
+
+    // The permutation is fetched 64 steps at a time with one coalesced vector load and
+    // handed to the scalar unit with v_readlane (row base = SGPR pair, lane offset = VGPR).
+    auto perm_block = [&](uint32_t b) -> int32_t {
+        const uint32_t j = b * 64u + lane;
+        return prow[j < S ? j : S - 1u];
+    };
+    auto row_load = [&](int32_t pv, uint32_t l) -> uint4 {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane(pv, l);
+        const char *rowp = bytes + (size_t)r * stride_bytes;  // scalar
+        return *reinterpret_cast<const uint4 *>(rowp + lane_off);
+    };
+
+    const uint32_t n_chunks = ((S + 63u) / 64u) * (64u / PC_UNROLL);
+    int32_t pv_cur = perm_block(0), pv_nxt = perm_block(1);
+    uint4 cur[PC_UNROLL], nxt[PC_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PC_UNROLL; ++u) cur[u] = row_load(pv_cur, u);
+
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        // issue the next chunk's row loads before folding this one
+        const uint32_t cn = c + 1u;
+        const uint32_t sub = (cn & (64u / PC_UNROLL - 1u)) * PC_UNROLL;
+        if (sub == 0u) {  // wave-uniform: next chunk starts a new block of 64 steps
+            pv_cur = pv_nxt;
+            pv_nxt = perm_block(cn / (64u / PC_UNROLL) + 1u);
+        }
+#pragma unroll
+        for (int u = 0; u < PC_UNROLL; ++u) nxt[u] = row_load(pv_cur, sub + u);
+
+#pragma unroll
+        for (int u = 0; u < PC_UNROLL; ++u) {
+            const uint32_t j = c * PC_UNROLL + u;  // steps >= S only touch lanes that are never stored
+            const uint4 row = cur[u];
+            acc_or.x |= row.x; acc_or.y |= row.y; acc_or.z |= row.z; acc_or.w |= row.w;
+            acc_and.x &= row.x; acc_and.y &= row.y; acc_and.z &= row.z; acc_and.w &= row.w;
+            const uint32_t packed = popc128(acc_or) | (popc128(acc_and) << 16);
+            const uint32_t total = wave_sum_u32(active ? packed : 0u);
+            parked = (lane == (j & 63u)) ? total : parked;
+        }
+        if ((c & (64u / PC_UNROLL - 1u)) == 64u / PC_UNROLL - 1u) {  // 64 totals parked: one coalesced store
+            const uint32_t jb = (c / (64u / PC_UNROLL)) * 64u;
+            if (jb + lane < S) out[jb + lane] = parked;
+        }
+#pragma unroll
+        for (int u = 0; u < PC_UNROLL; ++u) cur[u] = nxt[u];
+    }
+}
+
+__global__ __launch_bounds__(256) void pan_core_reduce_kernel(const uint32_t *__restrict__ partial,
+                                                             uint32_t n_partials, size_t n_out,
+                                                             int32_t *__restrict__ out_pan,
+                                                             int32_t *__restrict__ out_core) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_out;
+         e += (size_t)gridDim.x * blockDim.x) {
+        uint32_t pan = 0, core = 0;
+        for (uint32_t p = 0; p < n_partials; ++p) {
+            const uint32_t x = partial[(size_t)p * n_out + e];
+            pan += x & 0xFFFFu;
+            core += x >> 16;
+        }
+        out_pan[e] = (int32_t)pan;
+        out_core[e] = (int32_t)core;
+    }
+}
+
+__global__ __launch_bounds__(256) void presence_bitmap_kernel(const int32_t *__restrict__ rows,
+                                                             const int32_t *__restrict__ genomes,
+                                                             uint64_t n, uint32_t n_rows,
+                                                             uint32_t n_genomes, uint32_t stride,
+                                                             unsigned long long *__restrict__ bits) {
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
+         k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)rows[k], g = (uint32_t)genomes[k];
+        if (r >= n_rows || g >= n_genomes) continue;  // host entry point validates; never write out of bounds
+        atomicOr(&bits[(size_t)g * stride + (r >> 6)], 1ull << (r & 63u));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t pgx_bitmap_stride_words(uint32_t n_genes) {
+    const uint32_t words = (n_genes + 63) / 64;
+    const uint32_t s = (words + 15u) & ~15u;
+    return s ? s : 16u;
+}
+
+size_t pgx_pan_core_workspace_bytes(uint32_t n_genes, uint32_t n_genomes, uint32_t n_iter) {
+    const PanCoreGeom g = make_geom(n_genes);
+    return (size_t)g.partials * n_iter * n_genomes * sizeof(uint32_t);
+}
+
+int pgx_presence_bitmap_dev(pgx_ctx *ctx, const int32_t *d_rows, const int32_t *d_genomes,
+                            uint64_t n_records, uint32_t n_rows, uint32_t n_genomes,
+                            uint64_t *d_out_bits, void *stream_) {
+    PGX_REQUIRE(ctx && d_out_bits, "NULL argument");
+    PGX_REQUIRE(n_records == 0 || (d_rows && d_genomes), "NULL record arrays");
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t stride = pgx_bitmap_stride_words(n_rows);
+    PGX_HIP(hipMemsetAsync(d_out_bits, 0, (size_t)n_genomes * stride * 8, stream));
+    if (n_records == 0) return PGX_OK;
+    const uint64_t want = (n_records + 255) / 256;
+    const uint32_t grid = (uint32_t)(want < 4096 ? want : 4096);
+    {
+        ProfScope prof(ctx, "presence_bitmap_kernel", stream);
+        presence_bitmap_kernel<<<grid, 256, 0, stream>>>(d_rows, d_genomes, n_records, n_rows,
+                                                         n_genomes, stride,
+                                                         (unsigned long long *)d_out_bits);
+    }
+    PGX_HIP(hipGetLastError());
+    return PGX_OK;
+}
+
+int pgx_presence_bitmap(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, uint64_t n_records,
+                        uint32_t n_rows, uint32_t n_genomes, uint64_t *out_bits) {
+    PGX_REQUIRE(ctx && out_bits, "NULL argument");
+    PGX_REQUIRE(n_records == 0 || (rows && genomes), "NULL record arrays");
+    for (uint64_t k = 0; k < n_records; ++k)
+        PGX_REQUIRE((uint32_t)rows[k] < n_rows && (uint32_t)genomes[k] < n_genomes,
+                    "record with row or genome index out of range");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    const size_t nbits = (size_t)n_genomes * pgx_bitmap_stride_words(n_rows) * 8;
+    DevBuf d_rows, d_genomes, d_bits;
+    PGX_HIP(d_rows.alloc(n_records * 4));
+    PGX_HIP(d_genomes.alloc(n_records * 4));
+    PGX_HIP(d_bits.alloc(nbits));
+    if (n_records) {
+        PGX_HIP(hipMemcpyAsync(d_rows.p, rows, n_records * 4, hipMemcpyHostToDevice, ctx->stream));
+        PGX_HIP(hipMemcpyAsync(d_genomes.p, genomes, n_records * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int rc = pgx_presence_bitmap_dev(ctx, d_rows.as<int32_t>(), d_genomes.as<int32_t>(), n_records,
+                                     n_rows, n_genomes, d_bits.as<uint64_t>(), ctx->stream);
+    if (rc != PGX_OK) return rc;
+    if (nbits) PGX_HIP(hipMemcpyAsync(out_bits, d_bits.p, nbits, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uint32_t n_genomes,
+                     const int32_t *d_perms, uint32_t n_iter, int32_t *d_out_pan, int32_t *d_out_core,
+                     void *d_workspace, size_t workspace_bytes, void *stream_) {
+    PGX_REQUIRE(ctx, "NULL context");
+    if (n_iter == 0 || n_genomes == 0) return PGX_OK;
+    PGX_REQUIRE(d_bits && d_perms && d_out_pan && d_out_core && d_workspace, "NULL argument");
+    PGX_REQUIRE(workspace_bytes >= pgx_pan_core_workspace_bytes(n_genes, n_genomes, n_iter),
+                "workspace too small (see pgx_pan_core_workspace_bytes)");
+    PGX_REQUIRE(((uintptr_t)d_bits & 15u) == 0, "bitmap must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const PanCoreGeom g = make_geom(n_genes);
+    const uint64_t items = (uint64_t)n_iter * g.wps;  // per stripe
+    const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * PC_STRIPES;
+    PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
+    {
+        ProfScope prof(ctx, "pan_core_sweep_kernel", stream);
+        pan_core_sweep_kernel<<<(uint32_t)blocks, PC_WAVES * 64, 0, stream>>>(
+            (const uint4 *)d_bits, g.stride * 8, d_perms, n_iter, n_genomes, g.Ls, g.wps, g.Lw,
+            (uint32_t *)d_workspace);
+    }
+    PGX_HIP(hipGetLastError());
+    const size_t n_out = (size_t)n_iter * n_genomes;
+    const size_t want = (n_out + 255) / 256;
+    {
+        ProfScope prof(ctx, "pan_core_reduce_kernel", stream);
+        pan_core_reduce_kernel<<<(uint32_t)(want < 2048 ? want : 2048), 256, 0, stream>>>(
+            (const uint32_t *)d_workspace, g.partials, n_out, d_out_pan, d_out_core);
+    }
+    PGX_HIP(hipGetLastError());
+    return PGX_OK;
+}
+
+int pgx_pan_core(pgx_ctx *ctx, const uint64_t *bits, uint32_t n_genes, uint32_t n_genomes,
+                 const int32_t *perms, uint32_t n_iter, int32_t *out_pan, int32_t *out_core) {
+    PGX_REQUIRE(ctx, "NULL context");
+    if (n_iter == 0 || n_genomes == 0) return PGX_OK;
+    PGX_REQUIRE(bits && perms && out_pan && out_core, "NULL argument");
+    for (size_t k = 0; k < (size_t)n_iter * n_genomes; ++k)
+        PGX_REQUIRE((uint32_t)perms[k] < n_genomes, "permutation entry out of range");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    const size_t nbits = (size_t)n_genomes * pgx_bitmap_stride_words(n_genes) * 8;
+    const size_t nperm = (size_t)n_iter * n_genomes * 4;
+    const size_t nws = pgx_pan_core_workspace_bytes(n_genes, n_genomes, n_iter);
+    DevBuf d_bits, d_perms, d_pan, d_core, d_ws;
+    PGX_HIP(d_bits.alloc(nbits));
+    PGX_HIP(d_perms.alloc(nperm));
+    PGX_HIP(d_pan.alloc(nperm));
+    PGX_HIP(d_core.alloc(nperm));
+    PGX_HIP(d_ws.alloc(nws));
+    PGX_HIP(hipMemcpyAsync(d_bits.p, bits, nbits, hipMemcpyHostToDevice, ctx->stream));
+    PGX_HIP(hipMemcpyAsync(d_perms.p, perms, nperm, hipMemcpyHostToDevice, ctx->stream));
+    int rc = pgx_pan_core_dev(ctx, d_bits.as<uint64_t>(), n_genes, n_genomes, d_perms.as<int32_t>(),
+                              n_iter, d_pan.as<int32_t>(), d_core.as<int32_t>(), d_ws.p, nws, ctx->stream);
+    if (rc != PGX_OK) return rc;
+    PGX_HIP(hipMemcpyAsync(out_pan, d_pan.p, nperm, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipMemcpyAsync(out_core, d_core.p, nperm, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+}  // extern "C"

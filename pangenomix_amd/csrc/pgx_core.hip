@@ -1,0 +1,148 @@
+// libpgx: context, error reporting, device info.
+#include "pgx_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void pgx_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static hipEvent_t prof_event(pgx_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(pgx_ctx *c, const char *name, hipStream_t s) : ctx(c), stream(s) {
+    if (!ctx || !ctx->profiling) return;
+    for (size_t i = 0; i < ctx->prof.size(); ++i)
+        if (ctx->prof[i].name == name) slot = (int)i;
+    if (slot < 0) {
+        ctx->prof.emplace_back();
+        ctx->prof.back().name = name;
+        slot = (int)ctx->prof.size() - 1;
+    }
+    e0 = prof_event(ctx);
+    e1 = prof_event(ctx);
+    if (e0) (void)hipEventRecord(e0, stream);
+}
+
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    if (e1) (void)hipEventRecord(e1, stream);
+    ctx->prof[slot].pending.emplace_back(e0, e1);
+    ctx->prof[slot].launches++;
+}
+
+static void prof_resolve(pgx_ctx *ctx) {
+    for (auto &sl : ctx->prof) {
+        for (auto &pr : sl.pending) {
+            float ms = 0.f;
+            if (pr.first && pr.second && hipEventSynchronize(pr.second) == hipSuccess &&
+                hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+                sl.total_ms += ms;
+            if (pr.first) ctx->event_pool.push_back(pr.first);
+            if (pr.second) ctx->event_pool.push_back(pr.second);
+        }
+        sl.pending.clear();
+    }
+}
+
+extern "C" {
+
+int pgx_profile_enable(pgx_ctx *ctx, int on) {
+    PGX_REQUIRE(ctx, "NULL context");
+    ctx->profiling = on != 0;
+    return PGX_OK;
+}
+
+int pgx_profile_reset(pgx_ctx *ctx) {
+    PGX_REQUIRE(ctx, "NULL context");
+    prof_resolve(ctx);
+    ctx->prof.clear();
+    return PGX_OK;
+}
+
+int pgx_profile_count(pgx_ctx *ctx) {
+    if (!ctx) return 0;
+    return (int)ctx->prof.size();
+}
+
+int pgx_profile_read(pgx_ctx *ctx, int slot, char *name, size_t name_bytes, double *total_ms,
+                     uint64_t *launches) {
+    PGX_REQUIRE(ctx, "NULL context");
+    PGX_REQUIRE(slot >= 0 && slot < (int)ctx->prof.size(), "slot out of range");
+    prof_resolve(ctx);
+    const ProfSlot &sl = ctx->prof[slot];
+    if (name && name_bytes) snprintf(name, name_bytes, "%s", sl.name.c_str());
+    if (total_ms) *total_ms = sl.total_ms;
+    if (launches) *launches = sl.launches;
+    return PGX_OK;
+}
+
+int pgx_version(void) { return PGX_VERSION; }
+
+const char *pgx_last_error(void) { return g_err; }
+
+int pgx_ctx_create(int device_id, pgx_ctx **out) {
+    PGX_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        pgx_set_error("pgx_ctx_create: no usable HIP device (%s); libpgx has no CPU fallback",
+                      e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return PGX_ERR_NO_DEVICE;
+    }
+    PGX_REQUIRE(device_id >= 0 && device_id < n, "device_id out of range");
+    PGX_HIP(hipSetDevice(device_id));
+    pgx_ctx *ctx = new (std::nothrow) pgx_ctx();
+    if (!ctx) {
+        pgx_set_error("pgx_ctx_create: out of host memory");
+        return PGX_ERR_NOMEM;
+    }
+    ctx->device_id = device_id;
+    e = hipGetDeviceProperties(&ctx->prop, device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        pgx_set_error("pgx_ctx_create: %s", hipGetErrorString(e));
+        delete ctx;
+        return PGX_ERR_HIP;
+    }
+    *out = ctx;
+    return PGX_OK;
+}
+
+void pgx_ctx_destroy(pgx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device_id);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_resolve(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pgx_device_info(pgx_ctx *ctx, pgx_device_info_t *out) {
+    PGX_REQUIRE(ctx && out, "NULL argument");
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", ctx->prop.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", ctx->prop.gcnArchName);
+    out->device_id = ctx->device_id;
+    out->compute_units = ctx->prop.multiProcessorCount;
+    out->wavefront_size = ctx->prop.warpSize;
+    out->lds_bytes_per_block = (int32_t)ctx->prop.sharedMemPerBlock;
+    out->hbm_bytes = ctx->prop.totalGlobalMem;
+    out->clock_khz = ctx->prop.clockRate;
+    return PGX_OK;
+}
+
+}  // extern "C"

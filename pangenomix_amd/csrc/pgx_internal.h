@@ -1,0 +1,75 @@
+// Internal helpers shared by the libpgx translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/pgx.h"
+
+#include <string>
+#include <utility>
+#include <vector>
+
+// Optional per-kernel timing (pgx_profile_*): HIP events recorded on the launch stream
+// around each kernel, resolved when the caller reads the slots.
+struct ProfSlot {
+    std::string name;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct pgx_ctx {
+    int device_id;
+    hipStream_t stream;  // used by the host-pointer entry points
+    hipDeviceProp_t prop;
+    bool profiling = false;
+    std::vector<ProfSlot> prof;
+    std::vector<hipEvent_t> event_pool;
+};
+
+// RAII bracket: records start/stop events on `stream` when profiling is enabled.
+struct ProfScope {
+    pgx_ctx *ctx;
+    hipStream_t stream;
+    int slot = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(pgx_ctx *c, const char *name, hipStream_t s);
+    ~ProfScope();
+};
+
+void pgx_set_error(const char *fmt, ...);
+
+#define PGX_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            pgx_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,               \
+                          hipGetErrorString(e_));                                          \
+            return PGX_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define PGX_REQUIRE(cond, msg)                                                             \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            pgx_set_error("%s: %s", __func__, msg);                                        \
+            return PGX_ERR_INVALID;                                                        \
+        }                                                                                  \
+    } while (0)
+
+// RAII device buffer for the host-pointer entry points.
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <typename T>
+    T *as() {
+        return static_cast<T *>(p);
+    }
+};
+
+static inline uint32_t ceil_div_u32(uint32_t a, uint32_t b) { return (a + b - 1) / b; }

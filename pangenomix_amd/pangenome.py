@@ -1,0 +1,489 @@
+"""
+Pan-genome construction on MI355X: host side of the hot path.
+
+Drop-in mirror of the reference entry points in pangenomix/pangenome.py
+(file:line cited per function) for the path SURVEY.md §8 scopes:
+
+  build_cds_pangenome / build_noncoding_pangenome
+     consolidate_seqs              exact dedupe by sha256          (H1)
+   * cluster_with_cdhit            greedy clustering -> HIP (K1/K2) instead of
+                                   the `cd-hit` / `cd-hit-est` shell-out
+     rename_genes_and_alleles      .clstr -> <name>_C#A# names      (H2)
+     build_genetic_feature_tables  allele x genome, gene x genome   (H4)
+     LightSparseDataFrame.to_npz   .npz + .labels.txt               (H5)
+     extract_noncoding             GFF+FNA -> feature FASTA         (H6)
+
+Same names, positional order, defaults, intermediate files and return values.
+The only behavioural differences are deliberate: a failing
+clustering call raises instead of surfacing later as FileNotFoundError, and
+unknown `cdhit_args` keys are rejected instead of silently passed through.
+"""
+
+from __future__ import print_function
+import os
+import hashlib
+import subprocess as sp
+
+import numpy as np
+import scipy.sparse
+
+from . import sparse_utils
+
+LOG_RATE = 10  # reference pangenome.py:32
+CLUSTER_TYPES = {'cds': 'C', 'noncoding': 'T'}
+VARIANT_TYPES = {'allele': 'A', 'upstream': 'U', 'downstream': 'D'}
+_COMPLEMENT = str.maketrans('ACGTWSRYMKNacgtwsrymkn', 'TGCAWSYRKMNtgcawsyrkmn')
+_COMPLEMENT_KEYS = frozenset('ACGTWSRYMKNacgtwsrymkn')
+
+
+# ---------------------------------------------------------------------------
+# small helpers (reference pangenome.py:1938-1969, :2040-2059)
+# ---------------------------------------------------------------------------
+def __get_gene_from_allele__(allele):
+    """<name>_C#A# -> <name>_C# (reference :2040-2044: split on the last 'A')."""
+    return allele[:allele.rindex('A')] if 'A' in allele else ''
+
+
+def __get_genome_from_filename__(filepath):
+    """Basename without extension (reference :2046-2051)."""
+    return os.path.splitext(os.path.split(filepath)[1])[0]
+
+
+def __get_header_from_fasta_line__(line):
+    """First whitespace token minus '>' (reference :2053-2055)."""
+    return line.split()[0][1:].strip()
+
+
+def __hash_sequence__(seq):
+    return hashlib.sha256(seq.encode('utf-8')).digest()
+
+
+def reverse_complement(seq):
+    """Reference :1938-1941 (table :37-41); unknown bases raise KeyError there."""
+    for base in seq:
+        if base not in _COMPLEMENT_KEYS:
+            raise KeyError(base)
+    return seq.translate(_COMPLEMENT)[::-1]
+
+
+def create_feature_name(name, cluster_type, cluster_num, variant_type=None, variant_num=-1):
+    """<name>_<C|T><cluster>[<A|U|D><variant>] (reference :1944-1969)."""
+    short = name + '_' + CLUSTER_TYPES[cluster_type] + str(cluster_num)
+    if variant_type is not None and int(variant_num) >= 0:
+        short += VARIANT_TYPES[variant_type] + str(variant_num)
+    return short
+
+
+def list_faa_files(directory_path):
+    """*.faa in os.listdir order, unsorted (reference :407-423)."""
+    return [os.path.join(directory_path, f) for f in os.listdir(directory_path)
+            if f.endswith('.faa')]
+
+
+def find_matching_genome_files(gff_dir, fna_dir):
+    """(gff, fna) pairs sharing a basename, in FNA listing order (reference :318-334)."""
+    gff = {os.path.splitext(f)[0]: os.path.join(gff_dir, f)
+           for f in os.listdir(gff_dir) if f.endswith('.gff')}
+    pairs = []
+    for f in os.listdir(fna_dir):
+        if f.endswith('.fna') and os.path.splitext(f)[0] in gff:
+            pairs.append((gff[os.path.splitext(f)[0]], os.path.join(fna_dir, f)))
+    return pairs
+
+
+def _iter_fasta_records(path):
+    """Yields (header_token, [stripped sequence lines]) as the reference's line
+    scanners see them (:381-391, :638-656): a record starts at a line whose first
+    character is '>', sequence lines are .strip()-ed, lines before the first
+    header belong to an empty header."""
+    header, blocks = '', []
+    with open(path, 'r') as f:
+        for line in f:
+            if line[0] == '>':
+                yield header, blocks
+                header, blocks = __get_header_from_fasta_line__(line), []
+            else:
+                blocks.append(line.strip())
+    yield header, blocks
+
+
+def load_sequences_from_fasta(fasta, header_fxn=None, seq_fxn=None, filter_fxn=None):
+    """Header -> sequence dict (reference :1892-1916); full header line by default."""
+    out = {}
+    header, blocks = '', []
+
+    def flush():
+        seq = ''.join(blocks)
+        if header and seq and (filter_fxn is None or filter_fxn(header)):
+            out[header] = seq_fxn(seq) if seq_fxn else seq
+    with open(fasta, 'r') as f:
+        for line in f:
+            if line[0] == '>':
+                flush()
+                header = line.strip()[1:]
+                header = header_fxn(header) if header_fxn else header
+                blocks = []
+            else:
+                blocks.append(line.strip())
+    flush()
+    return out
+
+
+# ---------------------------------------------------------------------------
+# H1: exact-duplicate consolidation (reference :336-405)
+# ---------------------------------------------------------------------------
+def consolidate_seqs(genome_paths, nr_out, shared_headers_out, missing_headers_out=None):
+    """Merge genome FASTA files into one non-redundant FASTA.
+
+    Files are read in the order given; the first header seen for a sequence is
+    its representative and the record is written with its original line
+    wrapping. Returns ({sha256 digest: [headers]}, [headers without sequence]).
+    """
+    groups = {}     # digest -> headers in order observed (insertion order = encounter order)
+    missing = []
+    with open(nr_out, 'w+') as f_nr:
+        for path in genome_paths:
+            for header, blocks in _iter_fasta_records(path):
+                if not header:
+                    continue
+                seq = ''.join(blocks)
+                if not seq:
+                    missing.append(header)
+                    continue
+                digest = __hash_sequence__(seq)
+                known = groups.get(digest)
+                if known is None:
+                    groups[digest] = [header]
+                    f_nr.write('>' + header + '\n' + '\n'.join(blocks) + '\n')
+                else:
+                    known.append(header)
+    with open(shared_headers_out, 'w+') as f:
+        for headers in groups.values():
+            if len(headers) > 1:
+                f.write('\t'.join(headers) + '\n')
+    if missing_headers_out:
+        print('Headers without sequences:', len(missing))
+        with open(missing_headers_out, 'w+') as f:
+            for header in missing:
+                f.write(header + '\n')
+    return groups, missing
+
+
+# ---------------------------------------------------------------------------
+# K1/K2: greedy incremental clustering on the GPU
+# ---------------------------------------------------------------------------
+def cluster_with_cdhit(fasta_file, cdhit_out, cdhit_args={'-n': 5, '-c': 0.8}):
+    """Cluster a FASTA file; writes `cdhit_out` (representatives) and
+    `cdhit_out + '.clstr'` exactly where the reference's cd-hit call would
+    (reference :425-450). `.fna` input selects the nucleotide (cd-hit-est) rules.
+
+    The clustering itself runs in the HIP library (pangenomix_amd.cluster);
+    there is no CPU fallback: a missing library or GPU raises.
+    """
+    from . import cluster
+    cluster.cluster_fasta_to_clstr(fasta_file, cdhit_out, cdhit_args)
+
+
+# ---------------------------------------------------------------------------
+# H2: .clstr -> allele names (reference :453-560)
+# ---------------------------------------------------------------------------
+def _parse_clstr(clstr_file):
+    """Yields (cluster_num_str, member_num_str, header) per member line, using
+    exactly the tokens the reference consumes (:505-513, :716-724)."""
+    cluster_num = None
+    with open(clstr_file, 'r') as f:
+        for line in f:
+            if line[0] == '>':
+                cluster_num = line.split()[-1].strip()
+            else:
+                data = line.split()
+                yield cluster_num, data[0], data[2][1:-3]
+
+
+def rename_genes_and_alleles(clstr_file, nr_fasta_in, nr_fasta_out,
+                             feature_names_out, name='Test', cluster_type='cds',
+                             shared_headers_file=None, fastasort_path=None):
+    """Name every clustered sequence <name>_C#A# / <name>_T#A#, write the
+    name table, and rewrite the non-redundant FASTA with the new headers.
+    Returns {original header (incl. synonyms): allele name}."""
+    synonyms = {}
+    if shared_headers_file:
+        with open(shared_headers_file, 'r') as f:
+            for line in f:
+                headers = line.strip().split('\t')
+                synonyms[headers[0]] = headers[1:]
+
+    header_to_allele = {}
+    with open(feature_names_out, 'w+') as f_names:
+        for cluster_num, member_num, header in _parse_clstr(clstr_file):
+            allele = create_feature_name(name, cluster_type, cluster_num, 'allele', member_num)
+            header_to_allele[header] = allele
+            mapped = [header]
+            for syn in synonyms.get(header, ()):
+                header_to_allele[syn] = allele
+                mapped.append(syn)
+            f_names.write(allele + '\t' + '\t'.join(mapped).strip() + '\n')
+
+    tmp = nr_fasta_out + '.tmp'
+    with open(nr_fasta_in, 'r') as f_old, open(tmp, 'w+') as f_new:
+        keep = False
+        for line in f_old:
+            if line[0] == '>':
+                header = line[1:].strip()
+                allele = header_to_allele.get(header)
+                keep = allele is not None
+                if keep:
+                    f_new.write('>' + allele + '\n')
+                else:
+                    print('MISSING:', header)
+            elif keep:
+                f_new.write(line)
+    if nr_fasta_out == nr_fasta_in:
+        os.remove(nr_fasta_in)
+    os.rename(tmp, nr_fasta_out)
+
+    if fastasort_path:  # optional external Exonerate fastasort (reference :547-559)
+        print('Sorting sequences by header...')
+        with open(tmp, 'w+') as f_sort:
+            p = sp.Popen(['./' + fastasort_path, nr_fasta_out], stdout=f_sort, stderr=sp.PIPE)
+            _, stderr = p.communicate()
+            print(stderr)
+        if p.returncode == 1:
+            print('Aborting sort, exitcode', p.returncode)
+            os.remove(tmp)
+        else:
+            os.rename(tmp, nr_fasta_out)
+    return header_to_allele
+
+
+# ---------------------------------------------------------------------------
+# H3: header -> allele map (reference :683-740)
+# ---------------------------------------------------------------------------
+def load_header_to_allele(clstr_file=None, shared_header_file=None,
+                          header_to_allele=None, name='Test', cluster_type='cds'):
+    if header_to_allele is None:
+        full = {}
+        for cluster_num, member_num, header in _parse_clstr(clstr_file):
+            full[header] = create_feature_name(name, cluster_type, cluster_num, 'allele', member_num)
+    else:
+        full = dict(header_to_allele)
+    if shared_header_file:
+        with open(shared_header_file, 'r') as f:
+            for line in f:
+                headers = [x.strip() for x in line.split('\t')]
+                for alt in headers[1:]:
+                    full[alt] = full[headers[0]]
+    return full
+
+
+# ---------------------------------------------------------------------------
+# H4: allele x genome and gene x genome tables (reference :563-680)
+# ---------------------------------------------------------------------------
+def _first_occurrence_coo(rows, cols, n_rows, n_cols):
+    """COO with ones, duplicates dropped, triples in order of first insertion:
+    the order scipy's dok_matrix.tocoo() yields for the reference's loop
+    (:649-650), pinned by tests/golden/cds."""
+    rows = np.asarray(rows, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
+    flat = rows * max(n_cols, 1) + cols
+    _, first = np.unique(flat, return_index=True)
+    first.sort()
+    data = np.ones(first.size, dtype=np.int64)
+    return scipy.sparse.coo_matrix(
+        (data, (rows[first].astype(np.int32), cols[first].astype(np.int32))),
+        shape=(n_rows, n_cols))
+
+
+def build_genetic_feature_tables(clstr_file, genome_fasta_paths, name='Test', cluster_type='cds',
+                                 output_format='lsdf', shared_header_file=None,
+                                 header_to_allele=None, log_rate=LOG_RATE):
+    """Binary allele x genome and gene x genome tables as LSDFs.
+
+    Row labels are the lexicographically sorted allele names (so C100 < C10 <
+    C11 < C1 < C2, reference :615) and their consecutive-deduped gene prefixes
+    (:618-623); columns are the sorted genome basenames (:612). Genome files are
+    scanned in sorted(path) order (:635) and a record counts only if it has a
+    non-empty sequence (:643).
+    """
+    print('Loadings header-allele mappings...')
+    # NB the reference passes cluster_type into the `name` slot here (:608-609);
+    # harmless because the dict is always supplied on the hot path.
+    header_to_allele = load_header_to_allele(clstr_file, shared_header_file,
+                                             header_to_allele, cluster_type)
+    genome_order = sorted(__get_genome_from_filename__(p) for p in genome_fasta_paths)
+    print('Sorting alleles...')
+    allele_order = sorted(set(header_to_allele.values()))
+    print('Sorting clusters...')
+    gene_of_allele = np.empty(len(allele_order), dtype=np.int64)
+    gene_order, last = [], None
+    for i, allele in enumerate(allele_order):
+        gene = __get_gene_from_allele__(allele)
+        if gene != last:
+            gene_order.append(gene)
+            last = gene
+        gene_of_allele[i] = len(gene_order) - 1
+    print('Genomes:', len(genome_order))
+    print('Clusters:', len(gene_order))
+    print('Alleles:', len(allele_order))
+
+    allele_index = {a: i for i, a in enumerate(allele_order)}
+    header_index = {h: allele_index[a] for h, a in header_to_allele.items()}
+    genome_index = {}
+    for i, g in enumerate(genome_order):
+        genome_index.setdefault(g, i)      # list.index() semantics: first match
+
+    rec_allele, rec_genome = [], []
+    for i, path in enumerate(sorted(genome_fasta_paths)):
+        genome = __get_genome_from_filename__(path)
+        genome_i = genome_index[genome]
+        for header, blocks in _iter_fasta_records(path):
+            if not any(blocks):
+                continue
+            allele_i = header_index.get(header)
+            if allele_i is None:
+                print('MISSING:', header)
+                continue
+            rec_allele.append(allele_i)
+            rec_genome.append(genome_i)
+        if (i + 1) % log_rate == 0:
+            print('Updating genome', i + 1, ':', genome)
+
+    print('Building binary matrix...')
+    rec_allele = np.asarray(rec_allele, dtype=np.int64)
+    rec_genome = np.asarray(rec_genome, dtype=np.int64)
+    sp_alleles = _first_occurrence_coo(rec_allele, rec_genome, len(allele_order), len(genome_order))
+    sp_genes = _first_occurrence_coo(gene_of_allele[rec_allele] if rec_allele.size else rec_allele,
+                                     rec_genome, len(gene_order), len(genome_order))
+    df_alleles = sparse_utils.LightSparseDataFrame(allele_order, genome_order, sp_alleles)
+    df_genes = sparse_utils.LightSparseDataFrame(gene_order, genome_order, sp_genes)
+    if output_format == 'sparr':
+        raise NotImplementedError(
+            "output_format='sparr' is the legacy pandas-SparseArray format that the "
+            "reference itself no longer supports on pandas 2 (SURVEY App. B.8); use 'lsdf'")
+    return df_alleles, df_genes
+
+
+# ---------------------------------------------------------------------------
+# H6: non-coding feature extraction (reference :1187-1243)
+# ---------------------------------------------------------------------------
+def extract_noncoding(genome_gff, genome_fna, noncoding_out, flanking=(0, 0),
+                      allowed_features=['transcript', 'tRNA', 'rRNA', 'misc_binding']):
+    """Write the nucleotide sequence of every allowed GFF feature (PATRIC
+    flavour: contig column is 'accn|<contig>', 5 characters trimmed, :1221)."""
+    contigs = load_sequences_from_fasta(genome_fna, header_fxn=lambda x: x.split()[0])
+    with open(noncoding_out, 'w+') as f_out, open(genome_gff, 'r') as f_gff:
+        for line in f_gff:
+            if line[0] == '#' or len(line.strip()) == 0:
+                continue
+            contig, _src, ftype, start, stop, _score, strand, _phase, meta = line.split('\t')
+            contig = contig[5:]
+            start, stop = int(start), int(stop)
+            if ftype not in allowed_features or contig not in contigs:
+                continue
+            lo = max(0, start - 1 - flanking[0])
+            seq = contigs[contig][lo:stop + flanking[1]]
+            if strand == '-':
+                seq = reverse_complement(seq)
+            fields = [kv.split('=') for kv in meta.split(';')]
+            feature_id = {kv[0]: kv[1] for kv in fields}['ID']
+            wrapped = '\n'.join(seq[i:i + 70] for i in range(0, len(seq), 70))
+            f_out.write('>' + feature_id + '\n' + wrapped + '\n')
+
+
+# ---------------------------------------------------------------------------
+# entry points (reference :44-156, :159-316)
+# ---------------------------------------------------------------------------
+def _check_format(output_format):
+    if output_format not in {'lsdf', 'sparr'}:
+        print('Unrecognized output format, switching to lsdf')
+        return 'lsdf'
+    return output_format
+
+
+def _p(output_dir, name, suffix):
+    return (output_dir + '/' + name + suffix).replace('//', '/')
+
+
+def build_cds_pangenome(genome_faa_paths, output_dir, name='Test',
+                        cdhit_args={'-n': 5, '-c': 0.8}, fastasort_path=None,
+                        output_format='lsdf'):
+    """Protein pan-genome: dedupe -> cluster (HIP) -> name -> tables -> npz.
+    Output files and return value as the reference (:44-156)."""
+    output_format = _check_format(output_format)
+    print('Identifying non-redundant CDS sequences...')
+    nr_faa = _p(output_dir, name, '_nr.faa')
+    shared = _p(output_dir, name, '_redundant_headers.tsv')
+    missing = _p(output_dir, name, '_missing_headers.txt')
+    consolidate_seqs(genome_faa_paths, nr_faa, shared, missing)
+
+    cluster_with_cdhit(nr_faa, nr_faa + '.cdhit', cdhit_args)
+    os.remove(nr_faa + '.cdhit')
+    clstr = nr_faa + '.cdhit.clstr'
+
+    header_to_allele = rename_genes_and_alleles(
+        clstr, nr_faa, nr_faa, _p(output_dir, name, '_allele_names.tsv'), name=name,
+        cluster_type='cds', shared_headers_file=shared, fastasort_path=fastasort_path)
+    df_alleles, df_genes = build_genetic_feature_tables(
+        clstr, genome_faa_paths, name, cluster_type='cds',
+        output_format=output_format, header_to_allele=header_to_allele)
+
+    allele_npz = _p(output_dir, name, '_strain_by_allele') + '.npz'
+    gene_npz = _p(output_dir, name, '_strain_by_gene') + '.npz'
+    print('Saving', allele_npz, '...')
+    df_alleles.to_npz(allele_npz)
+    print('Saving', gene_npz, '...')
+    df_genes.to_npz(gene_npz)
+    return df_alleles, df_genes
+
+
+def build_noncoding_pangenome(genome_data, output_dir, name='Test', flanking=(0, 0),
+                              allowed_features=['transcript', 'tRNA', 'rRNA', 'misc_binding'],
+                              cdhit_args={'-n': 5, '-c': 0.8}, fastasort_path=None,
+                              output_format='lsdf', fna_output_footer='', overwrite_extract=False):
+    """Non-coding pan-genome from (gff, fna) pairs; nucleotide clustering
+    (cd-hit-est rules) because the merged file ends in .fna (reference :159-316)."""
+    output_format = _check_format(output_format)
+    print('Extracting non-coding sequences...')
+    nc_paths = []
+    for i, (gff, fna) in enumerate(genome_data):
+        genome = __get_genome_from_filename__(gff)
+        gdir = '/'.join(gff.split('/')[:-1]) + '/' if '/' in gff else ''
+        nc_dir = gdir + 'derived/'
+        if not os.path.exists(nc_dir):
+            os.mkdir(nc_dir)
+        nc = nc_dir + genome + '_noncoding' + fna_output_footer + '.fna'
+        nc_paths.append(nc)
+        if os.path.exists(nc) and not overwrite_extract:
+            print(i + 1, 'Using pre-existing noncoding sequences for', genome)
+        else:
+            print(i + 1, 'Extracting noncoding regions for', genome)
+            extract_noncoding(gff, fna, nc, flanking=flanking, allowed_features=allowed_features)
+
+    print('Identifying non-redundant non-coding sequences...')
+    nr_fna = _p(output_dir, name, '_noncoding_nr.fna')
+    shared = _p(output_dir, name, '_noncoding_redundant_headers.tsv')
+    missing = _p(output_dir, name, '_noncoding_missing_headers.txt')
+    consolidate_seqs(nc_paths, nr_fna, shared, missing)
+
+    cluster_with_cdhit(nr_fna, nr_fna + '.cdhit', cdhit_args)
+    os.remove(nr_fna + '.cdhit')
+    clstr = nr_fna + '.cdhit.clstr'
+
+    header_to_allele = rename_genes_and_alleles(
+        clstr, nr_fna, nr_fna, _p(output_dir, name, '_noncoding_allele_names.tsv'), name=name,
+        cluster_type='noncoding', shared_headers_file=shared, fastasort_path=fastasort_path)
+    df_alleles, df_genes = build_genetic_feature_tables(
+        clstr, nc_paths, name, cluster_type='noncoding',
+        output_format=output_format, header_to_allele=header_to_allele)
+    # plain lists on purpose; the maps are not refreshed (reference :292-293, App. B.5)
+    strip = '_noncoding' + fna_output_footer
+    df_alleles.columns = [x.replace(strip, '') for x in df_alleles.columns]
+    df_genes.columns = [x.replace(strip, '') for x in df_genes.columns]
+
+    allele_npz = _p(output_dir, name, '_strain_by_noncoding_allele') + '.npz'
+    gene_npz = _p(output_dir, name, '_strain_by_noncoding_gene') + '.npz'
+    print('Saving', allele_npz, '...')
+    df_alleles.to_npz(allele_npz)
+    print('Saving', gene_npz, '...')
+    df_genes.to_npz(gene_npz)
+    return df_alleles, df_genes

@@ -1,0 +1,96 @@
+"""
+LightSparseDataFrame (LSDF): labelled scipy-sparse container and its on-disk
+format, the output contract of the pangenome hot path.
+
+Mirrors the reference interface of pangenomix/sparse_utils.py
+(`LightSparseDataFrame` :182-364, `read_lsdf` :18-42) for the members that sit
+on the hot path: constructor, `.index/.columns/.data/.shape`,
+`to_npz`, `read_lsdf`, plus the small dense helpers downstream consumers use.
+
+On-disk contract (pinned by tests/golden/cds/expected/*.npz):
+  <f>.npz            scipy.sparse.save_npz of the COO matrix
+                     members: row int32, col int32, data int64, shape int64[2],
+                     format b'coo'
+  <f>.npz.labels.txt index labels then column labels, one per line
+"""
+
+import numpy as np
+import scipy.sparse
+
+
+def read_lsdf(npz_file, label_file=None):
+    """Load an LSDF from `<npz_file>` + `<npz_file>.labels.txt`.
+
+    Reference: sparse_utils.py:18-42 (labels are split by the matrix' row count).
+    """
+    data = scipy.sparse.load_npz(npz_file)
+    label_path = npz_file + '.labels.txt' if label_file is None else label_file
+    with open(label_path, 'r') as f:
+        labels = [line.strip() for line in f]
+    n_rows = data.shape[0]
+    return LightSparseDataFrame(labels[:n_rows], labels[n_rows:], data)
+
+
+class LightSparseDataFrame(object):
+    """scipy.sparse matrix (kept as COO) with string row / column labels."""
+
+    def __init__(self, index, columns, data):
+        # Reference: sparse_utils.py:184-208. A conversion failure is reported
+        # and leaves .data = nan there; here it is an error (the
+        # build raises where the reference prints and continues).
+        self.data = data.tocoo()
+        self.index = np.array(index)
+        self.columns = np.array(columns)
+        self.shape = self.data.shape
+        self.index_map = {label: i for i, label in enumerate(index)}
+        self.column_map = {label: i for i, label in enumerate(columns)}
+        if len(index) != self.shape[0]:
+            print('ERROR: Index length does not match data')
+        if len(columns) != self.shape[1]:
+            print('ERROR: Column length does no match data')
+
+    # -- output contract ---------------------------------------------------
+    def to_npz(self, npz_file, label_file=None):
+        """Write `<npz_file>` and its label file (reference :295-314)."""
+        label_path = npz_file + '.labels.txt' if label_file is None else label_file
+        with open(label_path, 'w+') as f:
+            f.write(''.join(str(x) + '\n' for x in self.index))
+            f.write(''.join(str(x) + '\n' for x in self.columns))
+        scipy.sparse.save_npz(npz_file, self.data.tocoo())
+
+    # -- small helpers used by downstream consumers ------------------------
+    def transpose(self):
+        return LightSparseDataFrame(self.columns, self.index, self.data.transpose())
+
+    def islice(self, i_indices=None, i_columns=None):
+        """Positional row / column selection (reference :238-269)."""
+        if i_indices is None and i_columns is None:
+            print('No indices or columns selected')
+            return None
+        new_index, new_columns, new_data = self.index, self.columns, self.data
+        if i_columns is not None:
+            new_columns = self.columns[i_columns]
+            new_data = new_data.tocsc()[:, i_columns]
+        if i_indices is not None:
+            new_index = self.index[i_indices]
+            new_data = new_data.tocsr()[i_indices, :]
+        return LightSparseDataFrame(new_index, new_columns, new_data)
+
+    def labelslice(self, indices=None, columns=None):
+        i_idx = None if indices is None else [self.index_map[x] for x in indices]
+        i_col = None if columns is None else [self.column_map[x] for x in columns]
+        return self.islice(i_idx, i_col)
+
+    def sum(self, axis='index'):
+        if axis in ('index', 0):
+            return np.asarray(self.data.sum(axis=1))[:, 0]
+        return np.asarray(self.data.sum(axis=0))[0, :]
+
+    def drop_empty(self, axis='index'):
+        if axis in ('index', 0):
+            return self.islice(i_indices=np.where(self.sum(0) > 0)[0])
+        return self.islice(i_columns=np.where(self.sum(1) > 0)[0])
+
+    @property
+    def values(self):
+        return self.data.toarray()

@@ -1,0 +1,92 @@
+"""K3 parity on the GPU: libpgx (HIP, through the C ABI) against the reference's own
+tables (tests/golden/pancore), against the CPU oracle on seeded inputs, and -- at
+BASELINE's full size -- through size-independent properties. Integer work: bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+import oracle
+from pangenomix_amd import pangenome_analysis as pa
+from pangenomix_amd import sparse_utils as su
+from pangenomix_amd import synth
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'pancore', '*.npz')))
+
+
+def bitmap_reference(row, col, G, S, stride):
+    bits = np.zeros((S, stride), dtype=np.uint64)
+    np.bitwise_or.at(bits, (col, row >> 6), np.uint64(1) << (row & 63).astype(np.uint64))
+    return bits
+
+
+@pytest.mark.parametrize('path', CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_entry_point_reproduces_reference_table(path, gpu_ctx):
+    z = np.load(path)
+    G, S = (int(x) for x in z['shape'])
+    coo = scipy.sparse.coo_matrix((np.ones(z['row'].size, dtype=np.int64), (z['row'], z['col'])), shape=(G, S))
+    lsdf = su.LightSparseDataFrame(['g%d' % i for i in range(G)], ['s%d' % i for i in range(S)], coo)
+    np.random.seed(int(z['seed']))
+    df = pa.estimate_pan_core_size(lsdf, z['perms'].shape[0], ctx=gpu_ctx)
+    assert df.values.dtype == np.float64
+    assert np.array_equal(df.values, z['expected'])
+    assert list(df.index) == list(z['index']) and list(df.columns) == list(z['columns'])
+
+
+@pytest.mark.parametrize('G,S,density,n_iter', [
+    (1, 1, 1.0, 1), (63, 5, 0.5, 3), (64, 64, 0.3, 4), (65, 65, 0.3, 4), (1000, 129, 0.1, 5),
+    (8200, 200, 0.02, 9), (70001, 31, 0.5, 6), (300000, 16, 0.3, 3)])
+def test_matches_oracle_on_seeded_inputs(G, S, density, n_iter, gpu_ctx):
+    rng = np.random.default_rng(G * 7 + S)
+    dense = rng.random((G, S)) < density
+    row, col = (a.astype(np.int32) for a in np.nonzero(dense))
+    perms = np.array([rng.permutation(S) for _ in range(n_iter)], dtype=np.int32)
+    bits = gpu_ctx.presence_bitmap(row, col, G, S)
+    assert np.array_equal(bits, bitmap_reference(row.astype(np.int64), col, G, S, bits.shape[1]))
+    pan, core = gpu_ctx.pan_core(bits, G, perms)
+    opan, ocore = oracle.pan_core(row, col, None, G, S, perms)
+    assert np.array_equal(pan, opan) and np.array_equal(core, ocore)
+
+
+def test_empty_inputs(gpu_ctx):
+    bits = gpu_ctx.presence_bitmap(np.zeros(0, np.int32), np.zeros(0, np.int32), 10, 3)
+    assert bits.shape == (3, 16) and not bits.any()
+    pan, core = gpu_ctx.pan_core(bits, 10, np.array([[2, 0, 1]], dtype=np.int32))
+    assert pan.tolist() == [[0, 0, 0]] and core.tolist() == [[0, 0, 0]]
+
+
+def test_rejects_bad_arguments(gpu_ctx):
+    from pangenomix_amd._native import PgxError
+    with pytest.raises(PgxError, match='out of range'):
+        gpu_ctx.presence_bitmap(np.array([10], np.int32), np.array([0], np.int32), 10, 3)
+    bits = gpu_ctx.presence_bitmap(np.array([1], np.int32), np.array([0], np.int32), 10, 3)
+    with pytest.raises(PgxError, match='permutation'):
+        gpu_ctx.pan_core(bits, 10, np.array([[0, 1, 3]], dtype=np.int32))
+
+
+def test_full_size_properties(gpu_ctx):
+    """BASELINE config 3 size (150k genes x 400 genomes, 1000 iterations): properties that
+    hold for every permutation, plus the oracle on a sample of the iterations."""
+    row, col, G = synth.pancore_matrix()
+    S, n_iter = 400, 1000
+    rng = np.random.default_rng(0)
+    perms = np.array([rng.permutation(S) for _ in range(n_iter)], dtype=np.int32)
+    bits = gpu_ctx.presence_bitmap(row, col, G, S)
+    pan, core = gpu_ctx.pan_core(bits, G, perms)
+    per_genome = np.bincount(col, minlength=S)
+    per_gene = np.bincount(row, minlength=G)
+    assert np.array_equal(pan[:, 0], per_genome[perms[:, 0]])       # first step = that genome's gene count
+    assert np.array_equal(core[:, 0], pan[:, 0])
+    assert (np.diff(pan, axis=1) >= 0).all() and (np.diff(core, axis=1) <= 0).all()
+    assert (pan[:, -1] == G).all()                                    # no empty rows -> union is everything
+    assert (core[:, -1] == (per_gene == S).sum()).all()               # intersection is order independent
+    assert (core <= pan).all()
+    sample = [0, 1, 499, 998, 999]
+    opan, ocore = oracle.pan_core(row, col, None, G, S, perms[sample])
+    assert np.array_equal(pan[sample], opan) and np.array_equal(core[sample], ocore)
+    # identical permutations give identical rows; reversing a permutation keeps the end points
+    pan2, core2 = gpu_ctx.pan_core(bits, G, perms[::-1].copy())
+    assert np.array_equal(pan2[::-1], pan) and np.array_equal(core2[::-1], core)
