@@ -1,10 +1,919 @@
-// K1/K2 placeholder while the greedy clustering kernels are being written.
+// K1: greedy incremental clustering with cd-hit's rules on gfx950.
+//
+// Replaces the reference's shell-out `cd-hit -i nr.faa -o ... -d 0 -n 5 -c 0.8`
+// (pangenome.py:444-450). The sequential rule being reproduced (oracle/cluster_ref.c):
+// sequences in stable descending-length order; query q joins the FIRST representative r
+// (created before q) that passes  word count >= required_aan  ->  diagonal test >=
+// required_aas  ->  banded alignment identity >= c,  candidates ordered by
+// (smallest shared word code, representative index); otherwise q becomes a representative.
+// Acceptance A(q, r) is a pure function of the pair, so the GPU evaluates pairs in bulk
+// and only the final "first accepted in key order" selection follows the greedy order.
+//
+// One SWEEP handles a batch of up to kBatchCap consecutive queries:
+//   index   direct-address CSR over the batch's distinct (word, query, multiplicity) entries
+//           (counting sort: histogram -> exclusive scan -> scatter)
+//   count   one workgroup per representative streams the representative's distinct-word
+//           list from HBM (coalesced), probes the CSR, and accumulates the short-word
+//           counters min(mult_q, mult_r) and the smallest shared code for all batch queries
+//           in LDS; pairs reaching required_aan are emitted
+//   diag    one wave per pair: 2-mer diagonal histogram in LDS, best band window
+//   align   one wave per pair: banded DP, one band column per lane, anti-diagonal
+//           wavefront, neighbours' cells exchanged with wave shuffles, identity carried
+//           along the best path (no traceback matrix)
+//   phase A = batch vs representatives that existed before the sweep, fully on device,
+//   phase B = batch vs the batch's own still-unassigned members; the in-order resolution
+//   of phase B runs on the host in rounds that only align edges to confirmed representatives.
+//
+// HBM layout: residues 1 byte/residue in sorted order; word lists (u32 code, u16 mult) at
+// the same offsets as the residues; everything stays resident for the whole call.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "cluster_tables.h"
 #include "pgx_internal.h"
 
+namespace {
+
+using namespace pgxc;
+
+constexpr uint32_t kBatchCap = 4096;   // queries per sweep = LDS counters per workgroup
+constexpr uint32_t kMaxLen = 32767;    // longest supported sequence
+constexpr uint32_t kSentinel = 0xFFFFFFFFu;
+constexpr uint32_t kDiagLdsCap = 4096;  // diagonals kept in LDS by the diag kernel
+constexpr int kMaxBand = 64;
+
+__constant__ int8_t kBlosum62_dev[kNAA1 * kNAA1] = PGXC_BLOSUM62_FLAT;
+
+enum : uint32_t { F_DIAG_PASS = 1, F_BAND_OK = 2, F_ACCEPT = 4, F_TOO_BIG = 8 };
+
+struct Pair {           // one (query, representative) candidate
+    uint32_t q;         // sorted sequence index of the query
+    uint32_t r;         // phase A: representative index; phase B: sorted sequence index
+    uint32_t cnt;       // short-word count
+    uint32_t minc;      // smallest shared word code (candidate order key)
+    int32_t best_sum, band_left, band_center, band_right;
+    int32_t iden;
+    uint32_t flags;
+};
+
+struct DevSeqs {
+    const uint8_t *res;     // residue indices, sorted order, concatenated
+    const uint64_t *off;    // [n+1]
+    const uint32_t *len;    // [n]
+    const uint32_t *wcode;  // distinct word codes, ascending, at off[k]
+    const uint16_t *wmult;  // multiplicities
+    const uint32_t *wcnt;   // [n] number of distinct words
+};
+
+// ----------------------------------------------------------------------------------------
+// words: encode all k-mers of a sequence, sort them in LDS (bitonic), collapse runs
+// ----------------------------------------------------------------------------------------
+template <int NCAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restrict__ res,
+                                                        const uint64_t *__restrict__ off,
+                                                        const uint32_t *__restrict__ len, uint32_t k0,
+                                                        uint32_t k1, int word_len,
+                                                        uint32_t *__restrict__ wcode,
+                                                        uint16_t *__restrict__ wmult,
+                                                        uint32_t *__restrict__ wcnt) {
+    __shared__ uint32_t keys[NCAP];
+    __shared__ uint32_t part[THREADS];
+    const uint32_t k = k0 + blockIdx.x;
+    if (k >= k1) return;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t o = off[k];
+    const uint8_t *s = res + o;
+    const uint32_t nw = len[k] - (uint32_t)word_len + 1u;
+    for (uint32_t i = tid; i < NCAP; i += THREADS) {
+        uint32_t key = kSentinel;
+        if (i < nw) {
+            key = 0;
+            for (int t = 0; t < word_len; ++t) key = key * kNAA1 + s[i + t];
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= NCAP; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < NCAP / 2; t += THREADS) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // run heads in this thread's contiguous chunk
+    constexpr uint32_t C = NCAP / THREADS;
+    const uint32_t beg = tid * C;
+    uint32_t heads = 0;
+    for (uint32_t i = beg; i < beg + C; ++i)
+        heads += (i < nw) && (i == 0 || keys[i] != keys[i - 1]);
+    part[tid] = heads;
+    __syncthreads();
+    for (uint32_t d = 1; d < THREADS; d <<= 1) {  // inclusive Hillis-Steele scan
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t idx = part[tid] - heads;
+    if (tid == THREADS - 1) wcnt[k] = part[tid];
+    for (uint32_t i = beg; i < beg + C; ++i) {
+        if ((i < nw) && (i == 0 || keys[i] != keys[i - 1])) {
+            uint32_t j = i + 1;
+            while (j < nw && keys[j] == keys[i]) ++j;
+            wcode[o + idx] = keys[i];
+            wmult[o + idx] = (uint16_t)(j - i);
+            ++idx;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// batch index: CSR by word code over the batch's distinct words
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void index_hist_kernel(DevSeqs S, uint32_t b0, uint32_t nb,
+                                                        uint32_t *__restrict__ bi_cnt) {
+    const uint32_t k = b0 + blockIdx.x;
+    if (blockIdx.x >= nb) return;
+    const uint64_t o = S.off[k];
+    const uint32_t n = S.wcnt[k];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&bi_cnt[S.wcode[o + i]], 1u);
+}
+
+__global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t b0, uint32_t nb,
+                                                           const uint32_t *__restrict__ bi_off,
+                                                           uint32_t *__restrict__ bi_fill,
+                                                           uint32_t *__restrict__ bi_ent) {
+    const uint32_t k = b0 + blockIdx.x;
+    if (blockIdx.x >= nb) return;
+    const uint64_t o = S.off[k];
+    const uint32_t n = S.wcnt[k];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t code = S.wcode[o + i];
+        const uint32_t pos = bi_off[code] + atomicAdd(&bi_fill[code], 1u);
+        bi_ent[pos] = (blockIdx.x << 16) | S.wmult[o + i];
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// count: short-word counting filter, counters for the whole batch staged in LDS
+// ----------------------------------------------------------------------------------------
+// MODE 0: table entries are representatives created before this sweep (rep index =
+//         position in rep_seq); every batch query is compared.
+// MODE 1: table entries are batch members still without a representative (list `ulist`);
+//         only later queries are compared, and a query that already has a phase-A hit keeps
+//         only candidates whose key could beat it (smaller shared word code).
+template <int MODE>
+__global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *__restrict__ table,
+                                                   const uint32_t *__restrict__ d_ntable,
+                                                   uint32_t ntable_host, uint32_t b0, uint32_t nb,
+                                                   const uint32_t *__restrict__ bi_off,
+                                                   const uint32_t *__restrict__ bi_ent,
+                                                   const int32_t *__restrict__ req_aan,
+                                                   const unsigned long long *__restrict__ best_old,
+                                                   Pair *__restrict__ pairs, uint32_t *__restrict__ n_pairs,
+                                                   uint32_t pair_cap,
+                                                   unsigned long long *__restrict__ visits) {
+    __shared__ uint32_t cnt[kBatchCap];
+    __shared__ uint32_t minc[kBatchCap];
+    __shared__ unsigned long long wg_visits;
+    const uint32_t ntable = d_ntable ? *d_ntable : ntable_host;
+    for (uint32_t r = blockIdx.x; r < ntable; r += gridDim.x) {
+        for (uint32_t q = threadIdx.x; q < nb; q += 256) { cnt[q] = 0u; minc[q] = kSentinel; }
+        if (threadIdx.x == 0) wg_visits = 0ull;
+        __syncthreads();
+        const uint32_t k = table[r];
+        const uint64_t o = S.off[k];
+        const uint32_t n = S.wcnt[k];
+        uint32_t my_visits = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t code = S.wcode[o + i];
+            const uint32_t m = S.wmult[o + i];
+            const uint32_t lo = bi_off[code], hi = bi_off[code + 1];
+            for (uint32_t e = lo; e < hi; ++e) {
+                const uint32_t ent = bi_ent[e];
+                const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
+                if (MODE == 1 && b0 + q <= k) continue;
+                atomicAdd(&cnt[q], m < mq ? m : mq);
+                atomicMin(&minc[q], code);
+                ++my_visits;
+            }
+        }
+        if (my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < nb; q += 256) {
+            const uint32_t c = cnt[q];
+            if (c == 0u || (int32_t)c < req_aan[b0 + q]) continue;
+            if (MODE == 1) {
+                const unsigned long long bo = best_old[q];
+                if (bo != ~0ull && minc[q] >= (uint32_t)(bo >> 32)) continue;
+            }
+            const uint32_t slot = atomicAdd(n_pairs, 1u);
+            if (slot < pair_cap) {
+                Pair p;
+                p.q = b0 + q; p.r = MODE == 0 ? r : k; p.cnt = c; p.minc = minc[q];
+                p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
+                pairs[slot] = p;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (MODE == 0) { if (wg_visits) atomicAdd(visits, wg_visits); }
+            else visits[k - b0] = wg_visits;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_unassigned_kernel(const unsigned long long *__restrict__ best_old,
+                                                                uint32_t b0, uint32_t nb,
+                                                                uint32_t *__restrict__ ulist,
+                                                                uint32_t *__restrict__ n_u) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q < nb && best_old[q] == ~0ull) ulist[atomicAdd(n_u, 1u)] = b0 + q;
+}
+
+// ----------------------------------------------------------------------------------------
+// diag: 2-mer diagonal histogram + best band (one wave per pair)
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t *total) {
+    uint32_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if ((int)lane >= d) x += y;
+    }
+    *total = __shfl(x, 63);
+    return x - v;
+}
+
+// Serial part of the diagonal test, exactly as the sequential rule states it (first best
+// window of `band_width` diagonals by complexity-weighted hits, centre = best single
+// diagonal seen while the window improved, edges trimmed). `d` packs hits | weighted<<16.
+template <typename DiagPtr>
+__device__ void band_from_histogram(DiagPtr d, int len1, int len2, int band_width, int required_aa1,
+                                    double cluster_thd, int *best_sum, int *bl, int *bc, int *br) {
+    const int nall = len1 + len2 - 1;
+    const int band_b = required_aa1 - 1 >= 0 ? required_aa1 - 1 : 0;
+    const int band_e = nall - band_b;
+    const int band_m = band_b + band_width - 1 < band_e ? band_b + band_width - 1 : band_e;
+    int best_score = 0, best_score2 = 0, max_diag2 = 0, imax = 0;
+    for (int i = band_b; i <= band_m; ++i) {
+        const uint32_t x = d[i];
+        const int s1 = (int)(x & 0xFFFFu), s2 = (int)(x >> 16);
+        best_score += s1; best_score2 += s2;
+        if (s2 > max_diag2) { max_diag2 = s2; imax = i; }
+    }
+    int from = band_b, end = band_m, score = best_score, score2 = best_score2;
+    for (int k = from, j = band_m + 1; j < band_e; ++j, ++k) {
+        const uint32_t xk = d[k], xj = d[j];
+        score += (int)(xj & 0xFFFFu) - (int)(xk & 0xFFFFu);
+        score2 += (int)(xj >> 16) - (int)(xk >> 16);
+        if (score2 > best_score2) {
+            from = k + 1; end = j; best_score = score; best_score2 = score2;
+            if ((int)(xj >> 16) > max_diag2) { max_diag2 = (int)(xj >> 16); imax = j; }
+        }
+    }
+    int mlen = imax;
+    if (imax > len1) mlen = nall - imax;
+    const int emax = (int)((1.0 - cluster_thd) * mlen) + 1;
+    for (int j = from; j < imax; ++j) {
+        const int s1 = (int)(d[j] & 0xFFFFu);
+        if ((imax - j) > emax || s1 < 1) { best_score -= s1; from++; } else break;
+    }
+    for (int j = end; j > imax; --j) {
+        const int s1 = (int)(d[j] & 0xFFFFu);
+        if ((j - imax) > emax || s1 < 1) { best_score -= s1; end--; } else break;
+    }
+    *bl = from - len1 + 1; *br = end - len1 + 1; *bc = imax - len1 + 1; *best_sum = best_score;
+}
+
+// rep_seq == nullptr: p.r is already a sequence index (phase B)
+__global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
+                                                 Pair *__restrict__ pairs,
+                                                 const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
+                                                 const int32_t *__restrict__ req_aa1,
+                                                 const int32_t *__restrict__ req_aas, int band_width,
+                                                 double cluster_thd, uint32_t *__restrict__ gscratch,
+                                                 uint32_t gscratch_stride) {
+    __shared__ uint32_t diag[kDiagLdsCap];
+    __shared__ uint32_t taap[kNAA1 * kNAA1 + 7];
+    __shared__ uint32_t abeg[kNAA1 * kNAA1 + 7];
+    __shared__ uint16_t alist[kDiagLdsCap];
+    const uint32_t lane = threadIdx.x;
+    uint32_t np = *d_npairs;
+    if (np > pair_cap) np = pair_cap;
+    constexpr int N2 = kNAA1 * kNAA1;
+    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
+        const Pair pr = pairs[p];
+        const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
+        const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
+        const uint8_t *s1 = S.res + S.off[k1];
+        const uint8_t *s2 = S.res + S.off[k2];
+        const int nall = len1 + len2 - 1;
+        const bool big = (uint32_t)nall > kDiagLdsCap || (uint32_t)len1 > kDiagLdsCap;
+        uint32_t *dg = big ? gscratch + (size_t)blockIdx.x * gscratch_stride : diag;
+        // the query's 2-mer position lists (global scratch tail for oversized queries)
+        uint32_t *al_big = big ? dg + 2 * (kMaxLen + 1) : nullptr;
+        for (int i = lane; i < nall; i += 64) dg[i] = 0u;
+        for (int c = lane; c < N2; c += 64) taap[c] = 0u;
+        __syncthreads();
+        for (int j = lane; j < len1 - 1; j += 64) atomicAdd(&taap[s1[j] * kNAA1 + s1[j + 1]], 1u);
+        __syncthreads();
+        {   // exclusive scan of the 441 bucket sizes, 7 per lane
+            uint32_t loc[7], sum = 0;
+            for (int t = 0; t < 7; ++t) { const int c = lane * 7 + t; loc[t] = c < N2 ? taap[c] : 0u; sum += loc[t]; }
+            uint32_t total, base = wave_excl_scan(sum, lane, &total);
+            for (int t = 0; t < 7; ++t) { const int c = lane * 7 + t; if (c < N2) { abeg[c] = base; taap[c] = 0u; } base += loc[t]; }
+        }
+        __syncthreads();
+        for (int j = lane; j < len1 - 1; j += 64) {
+            const int c = s1[j] * kNAA1 + s1[j + 1];
+            const uint32_t pos = abeg[c] + atomicAdd(&taap[c], 1u);
+            if (big) al_big[pos] = (uint32_t)j; else alist[pos] = (uint16_t)j;
+        }
+        __syncthreads();
+        for (int i = lane; i < len2 - 1; i += 64) {
+            const int c = s2[i] * kNAA1 + s2[i + 1];
+            const uint32_t inc = 1u | ((1u + (s2[i] != s2[i + 1])) << 16);
+            const uint32_t b = abeg[c], e = b + taap[c];
+            for (uint32_t t = b; t < e; ++t) {
+                const int j = big ? (int)al_big[t] : (int)alist[t];
+                atomicAdd(&dg[len1 - 1 + i - j], inc);
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int best_sum, bl, bc, br;
+            const int bw = band_width < len1 + len2 - 2 ? band_width : len1 + len2 - 2;
+            band_from_histogram(dg, len1, len2, bw, req_aa1[k1], cluster_thd, &best_sum, &bl, &bc, &br);
+            uint32_t fl = 0;
+            if (best_sum >= req_aas[k1]) fl |= F_DIAG_PASS;
+            if (!(br >= len2 || bl <= -len1 || bl > br)) fl |= F_BAND_OK;
+            if (br - bl + 1 > kMaxBand) fl |= F_TOO_BIG;
+            pairs[p].best_sum = best_sum; pairs[p].band_left = bl; pairs[p].band_center = bc;
+            pairs[p].band_right = br; pairs[p].flags = fl;
+        }
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// align: banded DP, one band column per lane, anti-diagonal wavefront (one wave per pair)
+// ----------------------------------------------------------------------------------------
+enum { BK_NONE = 0, BK_DIAG = 1, BK_LEFT = 2, BK_TOP = 3 };
+
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src_lane) {
+    const int lo = __shfl((int)(uint32_t)v, src_lane);
+    const int hi = __shfl((int)(v >> 32), src_lane);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// Banded alignment of query s1 (len1) against representative s2 (len2) over diagonals
+// [bl, br] (bc = centre). Cell (i, j1), j = j1 + i + bl, is computed by lane j1 at step
+// t = 2 i + j1; its neighbours (i, j1-1) and (i-1, j1+1) were computed one step earlier by
+// lanes j1-1 and j1+1, (i-1, j1) two steps earlier by the lane itself. Border cells carry
+// score = ext * distance and never count as gap continuations. Returns the number of
+// identical pairs on the best path into the end cell (wave-uniform).
+__device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2, int len1,
+                               int len2, int bl, int bc, int br, const int8_t *__restrict__ sub /*LDS 21x21*/) {
+    const int lane = threadIdx.x & 63;
+    const int bw = br - bl + 1;
+    const int j1 = lane;
+    const bool col = j1 < bw;
+    const int i_start = max(1, 1 - bl - j1);
+    const int i_end = min(len1, len2 - bl - j1);
+    const int i_start_left = max(1, 2 - bl - j1);
+    const int maxd = bc - bl;
+    const int dist = j1 > maxd ? j1 - maxd : maxd - j1;
+    const int64_t bonus = 4 - (dist & 3);
+    const int64_t gap = kScoreScale * kGapOpen, ext = kScoreScale * kGapExt;
+    int64_t sc = 0;
+    int bk = BK_NONE, id = 0;
+    const int t_last = 2 * len1 + bw - 1;
+    for (int t = 2; t <= t_last; ++t) {
+        const int64_t l_sc_n = shfl_i64(sc, (lane + 63) & 63);
+        const int l_meta = __shfl((id << 2) | bk, (lane + 63) & 63);
+        const int64_t r_sc_n = shfl_i64(sc, (lane + 1) & 63);
+        const int r_meta = __shfl((id << 2) | bk, (lane + 1) & 63);
+        const int d = t - j1;
+        const int i = d >> 1;
+        if (col && !(d & 1) && i >= i_start && i <= i_end) {
+            const int j = j1 + i + bl;
+            const int ci = s1[i - 1], cj = s2[j - 1];
+            int64_t sij = kScoreScale * (int64_t)sub[ci * kNAA1 + cj];
+            if (sij > 0) sij += bonus;
+            int64_t p_sc; int p_id;
+            if (i - 1 >= i_start) { p_sc = sc; p_id = id; }
+            else { p_sc = ext * (int64_t)((i - 1 == 0) ? (j - 1) : (i - 1)); p_id = 0; }
+            int64_t best = p_sc + sij;
+            int back = BK_DIAG, nid = p_id + (ci == cj);
+            const int64_t gap0 = (i == len1 || j == len2) ? ext : gap;
+            if (j1 > 0) {
+                int64_t l_sc; int l_bk, l_id;
+                if (i >= i_start_left) { l_sc = l_sc_n; l_bk = l_meta & 3; l_id = l_meta >> 2; }
+                else { l_sc = ext * (int64_t)i; l_bk = BK_NONE; l_id = 0; }
+                const int64_t s = l_sc + (l_bk == BK_LEFT ? ext : gap0);
+                if (s > best) { best = s; back = BK_LEFT; nid = l_id; }
+            }
+            if (j1 + 1 < bw) {
+                int64_t r_sc; int r_bk, r_id;
+                if (i - 1 >= 1) { r_sc = r_sc_n; r_bk = r_meta & 3; r_id = r_meta >> 2; }
+                else { r_sc = ext * (int64_t)j; r_bk = BK_NONE; r_id = 0; }
+                const int64_t s = r_sc + (r_bk == BK_TOP ? ext : gap0);
+                if (s > best) { best = s; back = BK_TOP; nid = r_id; }
+            }
+            sc = best; bk = back; id = nid;
+        }
+    }
+    int end_lane;
+    if (len2 - bl < len1) end_lane = 0;
+    else if (len1 + br < len2) end_lane = bw - 1;
+    else end_lane = len2 - len1 - bl;
+    return __shfl(id, end_lane);
+}
+
+// list == nullptr: align every pair with F_DIAG_PASS|F_BAND_OK (phase A) and fold accepted
+// ones into best_old[q - b0] = min(minc << 32 | rep index). list != nullptr: align the listed
+// pairs (phase B rounds) and write (iden, accepted) to out[w].
+__global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
+                                                   Pair *__restrict__ pairs,
+                                                   const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
+                                                   const uint32_t *__restrict__ list, uint32_t n_list,
+                                                   const int32_t *__restrict__ req_aa1, double cluster_thd,
+                                                   uint32_t b0, unsigned long long *__restrict__ best_old,
+                                                   int2 *__restrict__ out) {
+    __shared__ int8_t sub[kNAA1 * kNAA1];
+    for (int c = threadIdx.x; c < kNAA1 * kNAA1; c += 256) sub[c] = kBlosum62_dev[c];
+    __syncthreads();
+    uint32_t n = list ? n_list : *d_npairs;
+    if (!list && n > pair_cap) n = pair_cap;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (uint32_t w = blockIdx.x * 4 + wave; w < n; w += gridDim.x * 4) {
+        const uint32_t p = list ? list[w] : w;
+        const Pair pr = pairs[p];
+        if ((pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG)) != (F_DIAG_PASS | F_BAND_OK)) {
+            if (list && lane == 0) out[w] = make_int2(0, 0);
+            continue;
+        }
+        const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
+        const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
+        const int iden = band_align_wave(S.res + S.off[k1], S.res + S.off[k2], len1, len2, pr.band_left,
+                                         pr.band_center, pr.band_right, sub);
+        bool ok = iden >= req_aa1[k1];
+        if (ok) {
+            const float pc = (float)iden / (float)len1;
+            ok = !((double)pc < cluster_thd);
+        }
+        if (lane == 0) {
+            pairs[p].iden = iden;
+            if (ok) pairs[p].flags = pr.flags | F_ACCEPT;
+            if (list) out[w] = make_int2(iden, ok ? 1 : 0);
+            else if (ok) atomicMin(&best_old[k1 - b0], ((unsigned long long)pr.minc << 32) | pr.r);
+        }
+    }
+}
+
+}  // namespace
+
+// ========================================================================================
+// host side: one call = upload, word lists, sweeps, in-order resolution, download
+// ========================================================================================
+namespace {
+
+template <typename T>
+struct Pinned {  // page-locked host staging buffer
+    T *p = nullptr;
+    size_t cap = 0;
+    ~Pinned() { if (p) (void)hipHostFree(p); }
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = n + n / 2 + 1024;
+        return hipHostMalloc((void **)&p, cap * sizeof(T), hipHostMallocDefault);
+    }
+};
+
+struct Edge {            // phase-B candidate of one query, in key order
+    uint32_t u;          // sorted sequence index of the in-batch candidate representative
+    uint32_t minc;
+    uint32_t pidx;       // index into pairsB
+    int32_t iden;
+    uint8_t aligned, accepted;
+};
+
+enum : uint8_t { ST_OPEN = 0, ST_MEMBER = 1, ST_REP = 2 };
+
+#define LAUNCH_CHECK() PGX_HIP(hipGetLastError())
+
+template <int NCAP, int THREADS>
+int launch_words(pgx_ctx *ctx, hipStream_t st, const uint8_t *res, const uint64_t *off, const uint32_t *len,
+                 uint32_t k0, uint32_t k1, int word_len, uint32_t *wcode, uint16_t *wmult, uint32_t *wcnt) {
+    if (k1 <= k0) return PGX_OK;
+    ProfScope prof(ctx, "words_kernel", st);
+    words_kernel<NCAP, THREADS><<<k1 - k0, THREADS, 0, st>>>(res, off, len, k0, k1, word_len, wcode, wmult, wcnt);
+    LAUNCH_CHECK();
+    return PGX_OK;
+}
+
+}  // namespace
+
 extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const uint64_t *offsets,
-                                  uint32_t n, const pgx_cluster_params *params, int32_t *out_cluster,
+                                  uint32_t n_in, const pgx_cluster_params *P, int32_t *out_cluster,
                                   int32_t *out_member, float *out_identity, uint8_t *out_strand,
                                   uint32_t *out_n_clusters, pgx_cluster_stats *stats) {
-    pgx_set_error("pgx_cluster_greedy: not implemented yet");
-    return PGX_ERR_INTERNAL;
+    PGX_REQUIRE(ctx && P, "NULL argument");
+    PGX_REQUIRE(n_in == 0 || (residues && offsets), "NULL sequence arrays");
+    PGX_REQUIRE(out_cluster && out_member && out_identity, "NULL output arrays");
+    PGX_REQUIRE(P->alphabet == 0, "only protein rules (cd-hit) are implemented; nucleotide (cd-hit-est) is not");
+    PGX_REQUIRE(P->word_len >= 2 && P->word_len <= kMaxWordLen, "word_len must be 2..5");
+    PGX_REQUIRE(P->identity >= 0.4 && P->identity <= 1.0, "identity must be 0.4..1.0");
+    PGX_REQUIRE(P->band_width >= 1 && P->band_width <= kMaxBand, "band_width must be 1..64");
+    PGX_REQUIRE(P->min_length >= P->word_len - 1, "min_length must be at least word_len - 1");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    hipStream_t st = ctx->stream;
+    pgx_cluster_stats S{};
+    S.n_input = n_in;
+
+    // ---- A.2 / A.3 on the host: letters -> indices, stable descending-length order --------
+    std::vector<uint32_t> in_len(n_in);
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n_in; ++i) {
+        PGX_REQUIRE(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing");
+        uint32_t L = 0;
+        for (uint64_t p = offsets[i]; p < offsets[i + 1]; ++p) {
+            const uint8_t ch = residues[p] & 0xDF;  // fold case
+            L += (ch >= 'A' && ch <= 'Z');
+        }
+        in_len[i] = L;
+        if (L > max_len) max_len = L;
+        out_cluster[i] = -1; out_member[i] = -1; out_identity[i] = 0.f;
+        if (out_strand) out_strand[i] = 0;
+    }
+    if (max_len > kMaxLen) {
+        pgx_set_error("pgx_cluster_greedy: sequence of %u residues exceeds the supported maximum %u", max_len, kMaxLen);
+        return PGX_ERR_CAPACITY;
+    }
+    std::vector<uint32_t> bucket((size_t)max_len + 2, 0);
+    for (uint32_t i = 0; i < n_in; ++i)
+        if ((int)in_len[i] > P->min_length) bucket[max_len - in_len[i] + 1]++;
+    for (uint32_t l = 0; l <= max_len; ++l) bucket[l + 1] += bucket[l];
+    const uint32_t n = bucket[max_len + 1];
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n_in; ++i)
+        if ((int)in_len[i] > P->min_length) order[bucket[max_len - in_len[i]]++] = i;
+    if (out_n_clusters) *out_n_clusters = 0;
+    if (n == 0) { if (stats) *stats = S; return PGX_OK; }
+
+    std::vector<uint64_t> h_off((size_t)n + 1);
+    std::vector<uint32_t> h_len(n);
+    h_off[0] = 0;
+    for (uint32_t k = 0; k < n; ++k) { h_len[k] = in_len[order[k]]; h_off[k + 1] = h_off[k] + h_len[k]; }
+    const uint64_t total = h_off[n];
+    Pinned<uint8_t> h_res;
+    PGX_HIP(h_res.reserve(total));
+    for (uint32_t k = 0; k < n; ++k) {
+        uint8_t *dst = h_res.p + h_off[k];
+        for (uint64_t p = offsets[order[k]]; p < offsets[order[k] + 1]; ++p) {
+            const uint8_t ch = residues[p] & 0xDF;
+            if (ch >= 'A' && ch <= 'Z') *dst++ = (uint8_t)kAa2Idx[ch - 'A'];
+        }
+    }
+    // per-query thresholds in double, exactly as the sequential rule computes them
+    std::vector<int32_t> h_aa1(n), h_aas(n), h_aan(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        const int len = (int)h_len[k];
+        const int aa1 = (int)(P->identity * (double)len);
+        h_aa1[k] = aa1;
+        if (P->identity > 0.95) {
+            h_aas[k] = len - 2 + 1 - (len - aa1) * 2;
+            h_aan[k] = len - P->word_len + 1 - (len - aa1) * P->word_len;
+        } else {
+            h_aas[k] = (int)(P->aas_cutoff * (double)len);
+            h_aan[k] = (int)(P->aan_cutoff * (double)len);
+        }
+        S.sum_len_queries += (uint64_t)len;
+    }
+    S.n_clustered = n;
+
+    // ---- device buffers ------------------------------------------------------------------
+    uint32_t n_codes = 1;
+    for (int t = 0; t < P->word_len; ++t) n_codes *= kNAA1;
+    const uint32_t pair_cap = 4u << 20;
+    uint64_t max_batch_words = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += kBatchCap) {
+        const uint32_t b1 = std::min(n, b0 + kBatchCap);
+        max_batch_words = std::max<uint64_t>(max_batch_words, h_off[b1] - h_off[b0]);
+    }
+    const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsCap;
+    const uint32_t diag_grid = 2048, align_grid = 1024;
+    const uint32_t gs_stride = 3u * (kMaxLen + 1);
+
+    DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
+        d_bi_fill, d_bi_ent, d_best_old, d_ulist, d_counters, d_visits, d_pv, d_pairsA, d_pairsB, d_list, d_out,
+        d_scan_tmp, d_gscratch;
+    PGX_HIP(d_res.alloc(total + 16));
+    PGX_HIP(d_off.alloc(((size_t)n + 1) * 8));
+    PGX_HIP(d_len.alloc((size_t)n * 4));
+    PGX_HIP(d_wcode.alloc((total + 16) * 4));
+    PGX_HIP(d_wmult.alloc((total + 16) * 2));
+    PGX_HIP(d_wcnt.alloc((size_t)n * 4));
+    PGX_HIP(d_aa1.alloc((size_t)n * 4));
+    PGX_HIP(d_aas.alloc((size_t)n * 4));
+    PGX_HIP(d_aan.alloc((size_t)n * 4));
+    PGX_HIP(d_rep_seq.alloc((size_t)n * 4));
+    PGX_HIP(d_bi_cnt.alloc(((size_t)n_codes + 1) * 4));
+    PGX_HIP(d_bi_off.alloc(((size_t)n_codes + 1) * 4));
+    PGX_HIP(d_bi_fill.alloc((size_t)n_codes * 4));
+    PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
+    PGX_HIP(d_best_old.alloc(kBatchCap * 8));
+    PGX_HIP(d_ulist.alloc(kBatchCap * 4));
+    PGX_HIP(d_counters.alloc(16));
+    PGX_HIP(d_visits.alloc(8));
+    PGX_HIP(d_pv.alloc(kBatchCap * 8));
+    PGX_HIP(d_pairsA.alloc((size_t)pair_cap * sizeof(Pair)));
+    PGX_HIP(d_pairsB.alloc((size_t)pair_cap * sizeof(Pair)));
+    PGX_HIP(d_list.alloc(kBatchCap * 4));
+    PGX_HIP(d_out.alloc(kBatchCap * sizeof(int2)));
+    if (need_gscratch) PGX_HIP(d_gscratch.alloc((size_t)diag_grid * gs_stride * 4));
+    size_t scan_bytes = 0;
+    PGX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(),
+                                             (int)(n_codes + 1), st));
+    PGX_HIP(d_scan_tmp.alloc(scan_bytes));
+
+    PGX_HIP(hipMemcpyAsync(d_res.p, h_res.p, total, hipMemcpyHostToDevice, st));
+    PGX_HIP(hipMemcpyAsync(d_off.p, h_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
+    PGX_HIP(hipMemcpyAsync(d_len.p, h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    PGX_HIP(hipMemcpyAsync(d_aa1.p, h_aa1.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    PGX_HIP(hipMemcpyAsync(d_aas.p, h_aas.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    PGX_HIP(hipMemcpyAsync(d_aan.p, h_aan.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    PGX_HIP(hipMemsetAsync(d_visits.p, 0, 8, st));
+
+    // ---- word lists: size classes are contiguous because the order is by length ----------
+    {
+        const int wl = P->word_len;
+        auto first_with_words_le = [&](uint32_t cap) {  // first k whose word count fits `cap`
+            return (uint32_t)(std::partition_point(h_len.begin(), h_len.end(),
+                                                   [&](uint32_t L) { return L - wl + 1 > cap; }) - h_len.begin());
+        };
+        const uint32_t k32 = first_with_words_le(32768), k8 = first_with_words_le(8192),
+                       k2 = first_with_words_le(2048), k5 = first_with_words_le(512);
+        PGX_REQUIRE(k32 == 0, "sequence too long for the word sorter");
+        int rc;
+        uint8_t *r8 = d_res.as<uint8_t>(); uint64_t *o64 = d_off.as<uint64_t>(); uint32_t *l32 = d_len.as<uint32_t>();
+        uint32_t *wc = d_wcode.as<uint32_t>(); uint16_t *wm = d_wmult.as<uint16_t>(); uint32_t *wn = d_wcnt.as<uint32_t>();
+        if ((rc = launch_words<32768, 1024>(ctx, st, r8, o64, l32, 0, k8, wl, wc, wm, wn))) return rc;
+        if ((rc = launch_words<8192, 1024>(ctx, st, r8, o64, l32, k8, k2, wl, wc, wm, wn))) return rc;
+        if ((rc = launch_words<2048, 256>(ctx, st, r8, o64, l32, k2, k5, wl, wc, wm, wn))) return rc;
+        if ((rc = launch_words<512, 128>(ctx, st, r8, o64, l32, k5, n, wl, wc, wm, wn))) return rc;
+    }
+    DevSeqs DS{d_res.as<uint8_t>(), d_off.as<uint64_t>(), d_len.as<uint32_t>(),
+               d_wcode.as<uint32_t>(), d_wmult.as<uint16_t>(), d_wcnt.as<uint32_t>()};
+    std::vector<uint32_t> h_wcnt(n);
+    PGX_HIP(hipMemcpyAsync(h_wcnt.data(), d_wcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+
+    // ---- sweeps ---------------------------------------------------------------------------
+    std::vector<uint32_t> rep_seq;            // representative index -> sorted sequence index
+    std::vector<int32_t> cluster_of(n, -1);   // sorted sequence index -> cluster
+    std::vector<int32_t> iden_of(n, -1);      // identical residues against the representative, -1 = is one
+    Pinned<Pair> hA, hB;
+    Pinned<unsigned long long> h_best, h_pv;
+    Pinned<uint32_t> h_cnt, h_list;
+    Pinned<int2> h_out;
+    PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_pv.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(4));
+    PGX_HIP(h_list.reserve(kBatchCap)); PGX_HIP(h_out.reserve(kBatchCap));
+    uint32_t *d_nA = d_counters.as<uint32_t>(), *d_nB = d_nA + 1, *d_nU = d_nA + 2;
+    uint64_t visits_inbatch = 0;
+    std::vector<std::vector<Edge>> E(kBatchCap);
+    std::vector<uint8_t> status(kBatchCap);
+    std::vector<uint32_t> cursor(kBatchCap), member_of(kBatchCap), winner_minc(kBatchCap), order_idx;
+    std::vector<int32_t> old_iden(kBatchCap);
+    std::vector<uint8_t> won_new(kBatchCap);
+
+    for (uint32_t b0 = 0; b0 < n; b0 += kBatchCap) {
+        const uint32_t nb = std::min(kBatchCap, n - b0);
+        const uint32_t n_reps = (uint32_t)rep_seq.size();
+        S.sweeps++;
+        // index over the batch
+        PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));
+        PGX_HIP(hipMemsetAsync(d_bi_fill.p, 0, (size_t)n_codes * 4, st));
+        PGX_HIP(hipMemsetAsync(d_counters.p, 0, 16, st));
+        PGX_HIP(hipMemsetAsync(d_best_old.p, 0xFF, kBatchCap * 8, st));
+        PGX_HIP(hipMemsetAsync(d_pv.p, 0, kBatchCap * 8, st));
+        {
+            ProfScope prof(ctx, "index_hist_kernel", st);
+            index_hist_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_cnt.as<uint32_t>());
+        }
+        LAUNCH_CHECK();
+        {
+            ProfScope prof(ctx, "index_scan(hipcub)", st);
+            PGX_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, scan_bytes, d_bi_cnt.as<uint32_t>(),
+                                                     d_bi_off.as<uint32_t>(), (int)(n_codes + 1), st));
+        }
+        {
+            ProfScope prof(ctx, "index_scatter_kernel", st);
+            index_scatter_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_off.as<uint32_t>(),
+                                                     d_bi_fill.as<uint32_t>(), d_bi_ent.as<uint32_t>());
+        }
+        LAUNCH_CHECK();
+        // phase A: against the representatives that exist already
+        if (n_reps) {
+            {
+                ProfScope prof(ctx, "count_kernel<table>", st);
+                count_kernel<0><<<std::min(n_reps, 4096u), 256, 0, st>>>(
+                    DS, d_rep_seq.as<uint32_t>(), nullptr, n_reps, b0, nb, d_bi_off.as<uint32_t>(),
+                    d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, d_pairsA.as<Pair>(), d_nA, pair_cap,
+                    d_visits.as<unsigned long long>());
+            }
+            LAUNCH_CHECK();
+            {
+                ProfScope prof(ctx, "diag_kernel", st);
+                diag_kernel<<<diag_grid, 64, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), d_nA,
+                                                      pair_cap, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
+                                                      P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+            }
+            LAUNCH_CHECK();
+            {
+                ProfScope prof(ctx, "align_kernel", st);
+                align_kernel<<<align_grid, 256, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), d_nA,
+                                                         pair_cap, nullptr, 0, d_aa1.as<int32_t>(), P->identity, b0,
+                                                         d_best_old.as<unsigned long long>(), nullptr);
+            }
+            LAUNCH_CHECK();
+        }
+        // phase B: against the batch's own members that found no representative
+        compact_unassigned_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best_old.as<unsigned long long>(), b0, nb,
+                                                                    d_ulist.as<uint32_t>(), d_nU);
+        LAUNCH_CHECK();
+        {
+            ProfScope prof(ctx, "count_kernel<batch>", st);
+            count_kernel<1><<<std::min(nb, 4096u), 256, 0, st>>>(
+                DS, d_ulist.as<uint32_t>(), d_nU, 0, b0, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
+                d_aan.as<int32_t>(), d_best_old.as<unsigned long long>(), d_pairsB.as<Pair>(), d_nB, pair_cap,
+                d_pv.as<unsigned long long>());
+        }
+        LAUNCH_CHECK();
+        {
+            ProfScope prof(ctx, "diag_kernel", st);
+            diag_kernel<<<diag_grid, 64, 0, st>>>(DS, nullptr, d_pairsB.as<Pair>(), d_nB, pair_cap,
+                                                  d_aa1.as<int32_t>(), d_aas.as<int32_t>(), P->band_width,
+                                                  P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+        }
+        LAUNCH_CHECK();
+        PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 16, hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipStreamSynchronize(st));
+        const uint32_t nA = h_cnt.p[0], nB = h_cnt.p[1];
+        if (nA > pair_cap || nB > pair_cap) {
+            pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u > %u) in sweep at %u",
+                          nA, nB, pair_cap, b0);
+            return PGX_ERR_CAPACITY;
+        }
+        PGX_HIP(hA.reserve(nA)); PGX_HIP(hB.reserve(nB));
+        if (nA) PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        if (nB) PGX_HIP(hipMemcpyAsync(hB.p, d_pairsB.p, (size_t)nB * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipMemcpyAsync(h_best.p, d_best_old.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipMemcpyAsync(h_pv.p, d_pv.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipStreamSynchronize(st));
+
+        // ---- in-order resolution on the host ---------------------------------------------
+        for (uint32_t q = 0; q < nb; ++q) { E[q].clear(); status[q] = ST_OPEN; cursor[q] = 0; old_iden[q] = -1; won_new[q] = 0; }
+        for (uint32_t i = 0; i < nA; ++i) {
+            const Pair &p = hA.p[i];
+            if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) {
+                pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
+                return PGX_ERR_CAPACITY;
+            }
+            if ((p.flags & F_ACCEPT) && (((unsigned long long)p.minc << 32) | p.r) == h_best.p[p.q - b0])
+                old_iden[p.q - b0] = p.iden;
+        }
+        for (uint32_t i = 0; i < nB; ++i) {
+            const Pair &p = hB.p[i];
+            if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) {
+                pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
+                return PGX_ERR_CAPACITY;
+            }
+            if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK))
+                E[p.q - b0].push_back(Edge{p.r, p.minc, i, 0, 0, 0});
+        }
+        for (uint32_t q = 0; q < nb; ++q)
+            std::sort(E[q].begin(), E[q].end(), [](const Edge &a, const Edge &b) {
+                return a.minc != b.minc ? a.minc < b.minc : a.u < b.u;
+            });
+        std::vector<std::pair<uint32_t, uint32_t>> flight;  // (query, edge position) of the listed pairs
+        for (;;) {
+            flight.clear();
+            uint32_t open = 0;
+            for (uint32_t q = 0; q < nb; ++q) {
+                if (status[q] != ST_OPEN) continue;
+                const bool has_old = h_best.p[q] != ~0ull;
+                const uint32_t old_minc = (uint32_t)(h_best.p[q] >> 32);
+                bool pending = false, joined = false;
+                while (cursor[q] < E[q].size()) {
+                    Edge &e = E[q][cursor[q]];
+                    if (has_old && e.minc >= old_minc) break;  // the phase-A hit comes first from here on
+                    const uint8_t su = status[e.u - b0];
+                    if (su == ST_MEMBER) { cursor[q]++; continue; }
+                    if (su == ST_REP) {
+                        if (!e.aligned) { flight.emplace_back(q, cursor[q]); pending = true; break; }
+                        if (e.accepted) { joined = true; break; }
+                        cursor[q]++; continue;
+                    }
+                    pending = true; break;  // candidate not decided yet
+                }
+                if (pending) { open++; continue; }
+                if (joined) {
+                    const Edge &e = E[q][cursor[q]];
+                    status[q] = ST_MEMBER; member_of[q] = e.u; won_new[q] = 1; winner_minc[q] = e.minc;
+                    iden_of[b0 + q] = e.iden;
+                } else if (has_old) {
+                    status[q] = ST_MEMBER; member_of[q] = (uint32_t)(h_best.p[q] & 0xFFFFFFFFull); won_new[q] = 0;
+                    winner_minc[q] = old_minc; iden_of[b0 + q] = old_iden[q];
+                } else {
+                    status[q] = ST_REP;
+                }
+            }
+            if (!open) break;
+            if (flight.empty()) { pgx_set_error("pgx_cluster_greedy: resolution made no progress"); return PGX_ERR_INTERNAL; }
+            const uint32_t nl = (uint32_t)flight.size();
+            for (uint32_t w = 0; w < nl; ++w) h_list.p[w] = E[flight[w].first][flight[w].second].pidx;
+            PGX_HIP(hipMemcpyAsync(d_list.p, h_list.p, (size_t)nl * 4, hipMemcpyHostToDevice, st));
+            {
+                ProfScope prof(ctx, "align_kernel", st);
+                align_kernel<<<std::min(align_grid, (nl + 3) / 4), 256, 0, st>>>(
+                    DS, nullptr, d_pairsB.as<Pair>(), d_nB, pair_cap, d_list.as<uint32_t>(), nl, d_aa1.as<int32_t>(),
+                    P->identity, b0, nullptr, d_out.as<int2>());
+            }
+            LAUNCH_CHECK();
+            PGX_HIP(hipMemcpyAsync(h_out.p, d_out.p, (size_t)nl * sizeof(int2), hipMemcpyDeviceToHost, st));
+            PGX_HIP(hipStreamSynchronize(st));
+            for (uint32_t w = 0; w < nl; ++w) {
+                Edge &e = E[flight[w].first][flight[w].second];
+                e.aligned = 1; e.iden = h_out.p[w].x; e.accepted = (uint8_t)h_out.p[w].y;
+            }
+        }
+        // ---- close the sweep: number the new representatives in order, statistics --------
+        for (uint32_t q = 0; q < nb; ++q)
+            if (status[q] == ST_REP) {
+                cluster_of[b0 + q] = (int32_t)rep_seq.size();
+                rep_seq.push_back(b0 + q);
+                S.sum_len_reps += h_len[b0 + q];
+                S.rep_words += h_wcnt[b0 + q];
+                visits_inbatch += h_pv.p[q];
+            }
+        for (uint32_t q = 0; q < nb; ++q)
+            if (status[q] == ST_MEMBER)
+                cluster_of[b0 + q] = won_new[q] ? cluster_of[member_of[q]] : (int32_t)member_of[q];
+        auto tally = [&](const Pair &p, uint32_t len2) {
+            S.filter_pairs++;
+            if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
+                S.aligned_pairs++;
+                S.aligned_rep_len += len2;
+                S.dp_cells += (uint64_t)h_len[p.q] * (uint64_t)(p.band_right - p.band_left + 1);
+            }
+        };
+        for (uint32_t i = 0; i < nA; ++i) {  // candidates the one-by-one pass would have examined
+            const Pair &p = hA.p[i];
+            const uint32_t q = p.q - b0;
+            bool seen = status[q] == ST_REP;
+            if (!seen) seen = p.minc < winner_minc[q] || (p.minc == winner_minc[q] && (won_new[q] || p.r <= member_of[q]));
+            if (seen) tally(p, h_len[rep_seq[p.r]]);
+        }
+        for (uint32_t i = 0; i < nB; ++i) {
+            const Pair &p = hB.p[i];
+            const uint32_t q = p.q - b0;
+            if (status[p.r - b0] != ST_REP) continue;
+            bool seen = status[q] == ST_REP;
+            if (!seen) seen = p.minc < winner_minc[q] || (p.minc == winner_minc[q] && won_new[q] && p.r <= member_of[q]);
+            if (seen) tally(p, h_len[p.r]);
+        }
+        if (rep_seq.size() > n_reps)
+            PGX_HIP(hipMemcpyAsync(d_rep_seq.as<uint32_t>() + n_reps, rep_seq.data() + n_reps,
+                                   (rep_seq.size() - n_reps) * 4, hipMemcpyHostToDevice, st));
+        PGX_HIP(hipStreamSynchronize(st));  // rep_seq may reallocate before the copy is consumed
+    }
+
+    unsigned long long visits_table = 0;
+    PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
+    PGX_HIP(hipStreamSynchronize(st));
+    S.posting_visits = visits_table + visits_inbatch;
+    S.n_clusters = rep_seq.size();
+
+    // ---- outputs in the caller's order; member numbers follow the sorted order (A.3) ------
+    std::vector<uint32_t> members(rep_seq.size(), 0);
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t o = order[k];
+        const int32_t c = cluster_of[k];
+        out_cluster[o] = c;
+        out_member[o] = (int32_t)members[c]++;
+        out_identity[o] = iden_of[k] >= 0 ? (float)iden_of[k] / (float)h_len[k] : 0.f;
+    }
+    if (out_n_clusters) *out_n_clusters = (uint32_t)rep_seq.size();
+    if (stats) *stats = S;
+    return PGX_OK;
 }

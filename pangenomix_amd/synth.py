@@ -105,19 +105,21 @@ def protein_set(name):
 
 def pancore_matrix(n_genes=150000, n_genomes=400, seed=1):
     """Synthetic gene x genome presence matrix of SURVEY §8d: 2,000 genes at p=0.99, the rest
-    Beta(0.08, 3), empty rows dropped. Returns COO (row, col, n_rows)."""
+    Beta(0.08, 3); rows that come out empty are dropped and drawing continues until exactly
+    `n_genes` non-empty rows exist. Returns COO (row int32, col int32, n_genes)."""
     rng = np.random.default_rng(seed)
-    p = np.concatenate([np.full(2000, 0.99), rng.beta(0.08, 3.0, n_genes - 2000)])
-    rows, cols = [], []
-    chunk = 10000
-    for lo in range(0, n_genes, chunk):
-        m = rng.random((min(chunk, n_genes - lo), n_genomes)) < p[lo:lo + chunk, None]
+    rows, cols, have = [], [], 0
+    first = True
+    while have < n_genes:
+        chunk = 20000
+        p = rng.beta(0.08, 3.0, chunk)
+        if first:
+            p[:min(2000, chunk)] = 0.99
+            first = False
+        m = rng.random((chunk, n_genomes)) < p[:, None]
+        m = m[m.any(axis=1)][:n_genes - have]
         r, c = np.nonzero(m)
-        rows.append(r + lo)
+        rows.append(r + have)
         cols.append(c)
-    rows = np.concatenate(rows)
-    cols = np.concatenate(cols)
-    present = np.unique(rows)
-    remap = np.full(n_genes, -1, dtype=np.int64)
-    remap[present] = np.arange(present.size)
-    return remap[rows].astype(np.int32), cols.astype(np.int32), int(present.size)
+        have += m.shape[0]
+    return (np.concatenate(rows).astype(np.int32), np.concatenate(cols).astype(np.int32), int(n_genes))

@@ -1,0 +1,134 @@
+"""Known-answer tests of the clustering oracle (oracle/cluster_ref.c, the CPU restatement
+of cd-hit's greedy rule). cd-hit itself is not available offline,
+so these pin the properties that do not need it; parity with the real program is unpinned."""
+import numpy as np
+import pytest
+
+import oracle
+from pangenomix_amd import cluster, synth
+
+AA = 'ACDEFGHIKLMNPQRSTVWY'
+
+
+def pack(seqs):
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    return np.frombuffer(''.join(seqs).encode(), dtype=np.uint8), off
+
+
+def params(**kw):
+    args = {'-n': 5, '-c': 0.8}
+    args.update(kw)
+    return cluster.params_from_cdhit_args(args)
+
+
+def rand_seq(rng, n):
+    return ''.join(rng.choice(list(AA), size=n))
+
+
+def mutate(rng, s, n_sub):
+    s = list(s)
+    for p in rng.choice(len(s), size=n_sub, replace=False):
+        s[p] = AA[(AA.index(s[p]) + 1 + int(rng.integers(0, 19))) % 20]   # always a different letter
+    return ''.join(s)
+
+
+def run(seqs, **kw):
+    res, off = pack(seqs)
+    return oracle.cluster_greedy(res, off, params(**kw))
+
+
+def test_identical_sequences_share_one_cluster():
+    rng = np.random.default_rng(0)
+    s = rand_seq(rng, 120)
+    cl, mem, iden, _, nc, st = run([s, s, s])
+    assert nc == 1 and cl.tolist() == [0, 0, 0] and mem.tolist() == [0, 1, 2]
+    assert iden.tolist() == [0.0, 1.0, 1.0]
+
+
+@pytest.mark.parametrize('lo,hi', [(80, 120), (0, 40), (160, 200)])
+def test_threshold_straddle(lo, hi):
+    """Exactly int(0.8 L) identical residues joins; one fewer does not. The representative
+    contains no W and the variants carry one block of W's, so no alignment path can gain or
+    lose an identity: 160/200 and 159/200 identical residues by construction."""
+    rng = np.random.default_rng(1)
+    L = 200
+    rep = ''.join(rng.choice(list(AA.replace('W', '')), size=L + 20))   # longer: the representative
+    core = rep[:L]
+    ok = core[:lo] + 'W' * (hi - lo) + core[hi:]
+    bad = core[:lo - 1] + 'W' * (hi - lo + 1) + core[hi:] if lo else core[:lo] + 'W' * (hi - lo + 1) + core[hi + 1:]
+    cl, mem, iden, _, nc, st = run([rep, ok, bad])
+    assert cl.tolist() == [0, 0, 1] and nc == 2
+    assert iden.tolist() == [0.0, np.float32(160) / np.float32(200), 0.0]
+    assert st['filter_pairs'] == 2 and st['aligned_pairs'] == 2    # ok~rep accepted, bad~rep rejected at 159
+
+
+def test_short_sequences_are_discarded():
+    rng = np.random.default_rng(2)
+    seqs = [rand_seq(rng, 50), 'MKV', rand_seq(rng, 10), rand_seq(rng, 11)]
+    cl, mem, iden, _, nc, st = run(seqs)
+    assert cl[1] == -1 and cl[2] == -1 and mem[1] == -1
+    assert cl[0] == 0 and cl[3] == 1 and nc == 2
+    assert st['n_input'] == 4 and st['n_clustered'] == 2
+
+
+def test_representative_is_longest_and_clusters_are_numbered_by_creation():
+    rng = np.random.default_rng(3)
+    a, b = rand_seq(rng, 150), rand_seq(rng, 90)
+    a_short = a[:140]                  # 140/140 identical to a prefix of `a`
+    seqs = [b, a_short, a]             # input order scrambled
+    cl, mem, iden, _, nc, st = run(seqs)
+    assert nc == 2
+    assert cl.tolist() == [1, 0, 0]    # `a` (longest) creates cluster 0, `b` cluster 1
+    assert mem.tolist() == [0, 1, 0]   # member 0 = representative = longest
+    assert iden[1] == 1.0
+
+
+def test_equal_length_ties_keep_input_order():
+    rng = np.random.default_rng(4)
+    s = rand_seq(rng, 100)
+    t = mutate(rng, s, 2)
+    cl, mem, *_ = run([t, s])
+    assert cl.tolist() == [0, 0] and mem.tolist() == [0, 1]     # first in the file is the representative
+
+
+def test_case_and_non_letters():
+    rng = np.random.default_rng(5)
+    s = rand_seq(rng, 80)
+    cl, mem, iden, _, nc, _ = run([s, s.lower(), s[:40] + '*-' + s[40:]])
+    assert nc == 1 and iden.tolist() == [0.0, 1.0, 1.0]
+
+
+def test_counters_are_consistent():
+    res, off, _ = synth.protein_set('tiny').nr_arrays()
+    cl, mem, iden, _, nc, st = oracle.cluster_greedy(res, off, params())
+    lens = np.diff(off.astype(np.int64))
+    keep = lens > 10
+    assert st['n_clustered'] == keep.sum() and st['n_clusters'] == nc == cl.max() + 1
+    assert st['sum_len_queries'] == lens[keep].sum()
+    assert st['sum_len_reps'] == lens[(mem == 0)].sum()
+    assert st['aligned_pairs'] <= st['filter_pairs'] and st['dp_cells'] > 0
+    assert (iden[mem > 0] >= np.float32(0.8)).all()
+    for c in range(nc):                                    # representative = longest member
+        idx = np.flatnonzero(cl == c)
+        assert lens[idx[mem[idx] == 0][0]] == lens[idx].max()
+
+
+def test_rejects_unknown_cdhit_arguments():
+    with pytest.raises(ValueError, match='unsupported'):
+        cluster.params_from_cdhit_args({'-c': 0.8, '-aS': 0.9})
+    with pytest.raises(ValueError, match='-g 1'):
+        cluster.params_from_cdhit_args({'-c': 0.8, '-g': 1})
+
+
+def test_clstr_grammar(tmp_path):
+    rng = np.random.default_rng(6)
+    s = rand_seq(rng, 120)
+    seqs = [s, mutate(rng, s, 6), rand_seq(rng, 60)]
+    res, off = pack(seqs)
+    cl, mem, iden, strand, nc, _ = oracle.cluster_greedy(res, off, params())
+    path = str(tmp_path / 'x.clstr')
+    cluster.write_clstr(path, ['h0', 'h1', 'h2'], np.diff(off.astype(np.int64)), cl, mem, iden, strand)
+    assert open(path).read() == ('>Cluster 0\n0\t120aa, >h0... *\n1\t120aa, >h1... at 95.00%\n'
+                                 '>Cluster 1\n0\t60aa, >h2... *\n')
