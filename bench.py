@@ -2,16 +2,18 @@
 """bench.py -- headline benchmark of the pangenomix hot path on MI355X.
 
 One "step" = one pass of the hot path over the 400-genome workload (BASELINE.json
-configs[2], synthetic stand-in `cfg-3s`):
-  (a) greedy clustering at 0.8 identity of the non-redundant protein set   -> proteins/s
-  (b) 1000 pan/core rarefaction iterations on a 150,000 x 400 presence matrix -> iters/s
-with inputs resident in HBM when the timed region starts.
+configs[2]; the Bacteroides files are not available offline, so the deterministic synthetic
+stand-in `cfg-3s` of SURVEY.md §8d is used: 400 genomes x 4,500 CDS):
+  (a) K1  greedy clustering at 0.8 identity of the non-redundant protein set  -> proteins/s
+  (b) K3  1000 pan/core rarefaction iterations on a 150,000 x 400 presence matrix -> iters/s
+with the inputs resident in HBM when the timed region starts.
 
-  python bench.py [--gpus N --steps K --warmup W] [--workload cfg-3s|cfg-2s|small] [--skip-cluster]
+  python bench.py [--gpus N --steps K --warmup W] [--workload cfg-3s|cfg-2s|small|tiny]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL). Units are independent
-(pan/core iterations; for clustering each rank runs the whole set: "replicas only" until the
-sharded sweep of DESIGN.md lands), so scaling is "weak" and there is no data-path collective.
+`value` is proteins/s of (a) (N_nr sequences handed to the clustering call / its time);
+(b) is reported under "pan_core". N > 1 is launched by torch.distributed.run, one rank per
+GPU (RCCL): every rank runs the same work on its own copy (independent units, no data-path
+collective), times are max-reduced and `value` is the aggregate -> "weak" scaling.
 """
 import argparse
 import json
@@ -31,58 +33,82 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def cluster_algorithmic_bytes(st, bits=8):
+    """B_cluster of SURVEY §8d from the sequential-rule counters (b = bits per residue as
+    stored: 8 in this round's layout, 5 once the packed layout lands)."""
+    b = bits
+    return ((b * st['sum_len_queries'] + 7) // 8 + 4 * st['posting_visits'] + (b * st['aligned_rep_len'] + 7) // 8
+            + (b * st['sum_len_reps'] + 7) // 8 + 4 * st['rep_words'] + 12 * st['n_clustered'])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='cfg-3s')
     ap.add_argument('--pancore-genes', type=int, default=150000)
     ap.add_argument('--pancore-iters', type=int, default=1000)
-    ap.add_argument('--skip-cluster', action='store_true')
+    ap.add_argument('--cpu-sample-genomes', type=int, default=16)
     ap.add_argument('--skip-cpu', action='store_true')
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from pangenomix_amd import _native, cluster, synth
+    from pangenomix_amd import pangenome_analysis as pa
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (no CPU fallback)')
+        raise SystemExit('bench.py needs a GPU (there is no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
     ctx = _native.Context(local_rank)
-    info = ctx.device_info()
     if rank == 0:
-        log('device:', info)
+        log('device:', ctx.device_info())
+    stream = torch.cuda.current_stream().cuda_stream
 
-    # ---- inputs (synthetic, deterministic) -------------------------------------------
+    # ---- inputs (synthetic, deterministic), made resident in HBM ---------------------------
+    t0 = time.perf_counter()
+    pset = synth.protein_set(args.workload)
+    res, off, n_raw = pset.nr_arrays(progress=100 if rank == 0 else None)
+    n_nr = off.size - 1
+    params = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
+    d_res = torch.from_numpy(res.copy()).to(dev)
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     S = 400
     row, col, G = synth.pancore_matrix(args.pancore_genes, S, seed=1)
     n_iter = args.pancore_iters
     np.random.seed(0)
-    from pangenomix_amd import pangenome_analysis as pa
     perms = pa.draw_permutations(S, n_iter)
     stride = _native.lib().pgx_bitmap_stride_words(G)
-    d_row = torch.from_numpy(row).to(dev)
-    d_col = torch.from_numpy(col).to(dev)
+    d_row, d_col = torch.from_numpy(row).to(dev), torch.from_numpy(col).to(dev)
     d_bits = torch.zeros((S, stride), dtype=torch.int64, device=dev)
     d_perms = torch.from_numpy(perms).to(dev)
     d_pan = torch.empty((n_iter, S), dtype=torch.int32, device=dev)
     d_core = torch.empty((n_iter, S), dtype=torch.int32, device=dev)
     ws_bytes = _native.lib().pgx_pan_core_workspace_bytes(G, S, n_iter)
     d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    if rank == 0:
+        log('inputs: %s -> %d raw records, %d non-redundant, %.1f M residues; pan/core %d x %d; %.1f s'
+            % (args.workload, n_raw, n_nr, res.size / 1e6, G, S, time.perf_counter() - t0))
 
-    def pancore_step():
+    last = {}
+
+    def step():
+        t = time.perf_counter()
+        last['cluster'] = ctx.cluster_greedy_dev(d_res.data_ptr(), d_off.data_ptr(), n_nr, res.size, params, stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         ctx.presence_bitmap_dev(d_row.data_ptr(), d_col.data_ptr(), row.size, G, S, d_bits.data_ptr(), stream)
         ctx.pan_core_dev(d_bits.data_ptr(), G, S, d_perms.data_ptr(), n_iter, d_pan.data_ptr(),
                          d_core.data_ptr(), d_ws.data_ptr(), ws_bytes, stream)
+        torch.cuda.synchronize()
+        return t1 - t, time.perf_counter() - t1
 
     def barrier():
         torch.cuda.synchronize()
@@ -91,59 +117,82 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        pancore_step()
+        step()
     barrier()
     ctx.profile(True)
     ctx.profile_reset()
+    t_cluster = t_pancore = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pancore_step()
+        a, b = step()
+        t_cluster += a
+        t_pancore += b
     barrier()
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, t_cluster, t_pancore], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # parity spot-check of what was just timed (oracle as the checker only)
-    pan = d_pan.cpu().numpy()
-    core = d_core.cpu().numpy()
+        dt, t_cluster, t_pancore = (float(x) for x in t.tolist())
 
     if rank == 0:
         import oracle
+        steps = args.steps
+        cl, mem, iden, _, n_clusters, st = last['cluster']
+        # parity spot checks of what was just timed (the oracle is the checker only)
+        pan, core = d_pan.cpu().numpy(), d_core.cpu().numpy()
         sample = [0, n_iter - 1]
         opan, ocore = oracle.pan_core(row, col, None, G, S, perms[sample])
         assert np.array_equal(pan[sample], opan) and np.array_equal(core[sample], ocore), 'pan/core parity'
-        ms_step = dt / args.steps * 1e3
-        sweep_ms, sweep_n = prof['pan_core_sweep_kernel']
-        sweep_avg = sweep_ms / sweep_n
+
+        kern = {k: (v[0] / steps, v[1] // steps) for k, v in prof.items()}   # per step: (ms, launches)
+        sweep_ms = prof['pan_core_sweep_kernel'][0] / prof['pan_core_sweep_kernel'][1]
         words = (G + 63) // 64
-        alg_bytes = n_iter * (S * words * 8 + 2 * S * 4) + n_iter * S * 4
-        achieved = alg_bytes / (sweep_avg * 1e-3) / 1e9
+        pc_bytes = n_iter * (S * words * 8 + 2 * S * 4) + n_iter * S * 4
+        pc_gbs = pc_bytes / (sweep_ms * 1e-3) / 1e9
+        cl_bytes = cluster_algorithmic_bytes(st)
+        cl_gbs = cl_bytes / (t_cluster / steps) / 1e9
+
         cpu = None
         if not args.skip_cpu:
+            sub = synth.ProteinSet(args.cpu_sample_genomes, pset.cds, pset.F, pset.C, pset.seed)
+            sres, soff, _ = sub.nr_arrays()
+            t1 = time.perf_counter()
+            ocl = oracle.cluster_greedy(sres, soff, params)
+            cdt = time.perf_counter() - t1
             k = 20
             t1 = time.perf_counter()
             oracle.pan_core(row, col, None, G, S, perms[:k])
-            cdt = time.perf_counter() - t1
-            cpu = {'value': k / cdt, 'unit': 'pan/core iters/s', 'cores': 1, 'kind': 'port',
-                   'sample': '%d of %d iterations, oracle/pancore_ref.c (dense incidence loop of '
-                             'pangenome_analysis.py:81-90), same matrix' % (k, n_iter)}
+            pdt = time.perf_counter() - t1
+            cpu = {'value': (soff.size - 1) / cdt, 'unit': 'proteins/s', 'cores': 1, 'kind': 'port',
+                   'sample': 'oracle/cluster_ref.c (sequential restatement of cd-hit) on the non-redundant set of '
+                             'the first %d of %d genomes: %d sequences, %d clusters, %.1f s; cd-hit itself is not '
+                             'installed. NB the per-sequence cost grows with the table, so the full-set CPU rate '
+                             'is lower.' % (args.cpu_sample_genomes, pset.n_genomes, soff.size - 1, ocl[4], cdt),
+                   'pan_core': {'value': k / pdt, 'unit': 'iters/s', 'cores': 1,
+                                'sample': '%d of %d iterations, oracle/pancore_ref.c (dense incidence loop of '
+                                          'pangenome_analysis.py:81-90)' % (k, n_iter)}}
         line = {
-            'metric': 'pan/core iters/sec, 400-genome set',
-            'value': world * n_iter * args.steps / dt, 'unit': 'iters/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u64',
-            'data': 'synthetic',
-            'config': {'workload': 'pan/core 1000 iterations on synthetic %d x %d presence matrix '
-                                   '(SURVEY 8d, seed 1)' % (G, S)},
-            'roofline': {'bound': 'hbm', 'kernel': 'pan_core_sweep_kernel', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'avg_kernel_ms': sweep_avg, 'algorithmic_bytes': alg_bytes},
+            'metric': 'proteins/sec clustered at 0.8 identity + pan/core iters/sec, 400-genome set',
+            'value': world * n_nr * steps / t_cluster, 'unit': 'proteins/s', 'n_gpus': world, 'steps': steps,
+            'warmup': args.warmup, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'config': {'workload': '%s: %d genomes x %d CDS synthetic (SURVEY 8d), %d raw records -> %d '
+                                   'non-redundant proteins, %d clusters at -c 0.8 -n 5; pan/core %d iterations '
+                                   'on synthetic %d x %d matrix' % (args.workload, pset.n_genomes, pset.cds, n_raw,
+                                                                    n_nr, n_clusters, n_iter, G, S),
+                       'parallelism': 'replicas x%d' % world},
+            'pan_core': {'value': world * n_iter * steps / t_pancore, 'unit': 'iters/s',
+                         'ms': t_pancore / steps * 1e3},
+            'cluster': {'ms': t_cluster / steps * 1e3, 'raw_records_per_s': world * n_raw * steps / t_cluster,
+                        'algorithmic_bytes': cl_bytes, 'achieved_GBs': cl_gbs, 'frac_hbm': cl_gbs / HBM_PEAK_GBS,
+                        'dp_cells_per_s': st['dp_cells'] / (t_cluster / steps), 'stats': st},
+            'roofline': {'bound': 'hbm', 'kernel': 'pan_core_sweep_kernel', 'achieved': pc_gbs,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': pc_gbs / HBM_PEAK_GBS, 'traffic': None,
+                         'avg_kernel_ms': sweep_ms, 'algorithmic_bytes': pc_bytes},
             'cpu_baseline': cpu,
-            'kernels_ms': {k_: v[0] / max(v[1], 1) for k_, v in prof.items()},
+            'kernels_ms_per_step': {k_: {'ms': round(v[0], 4), 'launches': v[1]} for k_, v in sorted(kern.items())},
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -62,6 +62,8 @@ SIGNATURES = {
                                    C.c_size_t, _P]),
     'pgx_cluster_greedy': (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(ClusterParams), _P, _P, _P, _P,
                                      C.POINTER(C.c_uint32), C.POINTER(ClusterStats)]),
+    'pgx_cluster_greedy_dev': (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint64, C.POINTER(ClusterParams), _P, _P,
+                                         _P, _P, C.POINTER(C.c_uint32), C.POINTER(ClusterStats), _P]),
 }
 
 _lib = None
@@ -195,6 +197,21 @@ class Context(object):
         check(lib().pgx_cluster_greedy(self._h, _ptr(residues), _ptr(offsets), n, C.byref(params),
                                        _ptr(out_cluster), _ptr(out_member), _ptr(out_identity),
                                        _ptr(out_strand), C.byref(n_clusters), C.byref(stats)))
+        return out_cluster, out_member, out_identity, out_strand, int(n_clusters.value), stats.as_dict()
+
+
+    def cluster_greedy_dev(self, d_residues, d_offsets, n, total_bytes, params, stream=0):
+        """Sequences resident in HBM (raw device addresses); outputs are host arrays."""
+        out_cluster = np.empty(n, dtype=np.int32)
+        out_member = np.empty(n, dtype=np.int32)
+        out_identity = np.empty(n, dtype=np.float32)
+        out_strand = np.zeros(n, dtype=np.uint8)
+        n_clusters = C.c_uint32(0)
+        stats = ClusterStats()
+        check(lib().pgx_cluster_greedy_dev(self._h, d_residues, d_offsets, int(n), int(total_bytes),
+                                           C.byref(params), _ptr(out_cluster), _ptr(out_member),
+                                           _ptr(out_identity), _ptr(out_strand), C.byref(n_clusters),
+                                           C.byref(stats), stream))
         return out_cluster, out_member, out_identity, out_strand, int(n_clusters.value), stats.as_dict()
 
 

@@ -40,6 +40,7 @@ namespace {
 using namespace pgxc;
 
 constexpr uint32_t kBatchCap = 4096;   // queries per sweep = LDS counters per workgroup
+constexpr uint32_t kBlockCap = 512;    // unassigned members resolved together inside a sweep
 constexpr uint32_t kMaxLen = 32767;    // longest supported sequence
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kDiagLdsCap = 4096;  // diagonals kept in LDS by the diag kernel
@@ -67,6 +68,54 @@ struct DevSeqs {
     const uint16_t *wmult;  // multiplicities
     const uint32_t *wcnt;   // [n] number of distinct words
 };
+
+// ----------------------------------------------------------------------------------------
+// prep: letter count per input sequence, then gather + encode into sorted order
+// ----------------------------------------------------------------------------------------
+__constant__ int8_t kAa2Idx_dev[26] = {0, 2, 4, 3, 6, 13, 7, 8, 9, 20, 11, 10, 12,
+                                       2, 20, 14, 5, 1, 15, 16, 20, 19, 17, 20, 18, 6};
+
+__device__ __forceinline__ bool is_letter(uint8_t ch) {
+    ch &= 0xDF;
+    return ch >= 'A' && ch <= 'Z';
+}
+
+// one wave per input sequence
+__global__ __launch_bounds__(256) void seq_len_kernel(const uint8_t *__restrict__ res,
+                                                     const uint64_t *__restrict__ off, uint32_t n,
+                                                     uint32_t *__restrict__ len) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const uint64_t b = off[i], e = off[i + 1];
+    uint32_t c = 0;
+    for (uint64_t p = b + lane; p < e; p += 64) c += is_letter(res[p]);
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if (lane == 0) len[i] = c;
+}
+
+// one wave per sorted sequence: copy the letters of input sequence order[k] to out_off[k],
+// mapped to residue indices (non-letters are dropped, so the copy compacts with a ballot)
+__global__ __launch_bounds__(256) void encode_gather_kernel(const uint8_t *__restrict__ in,
+                                                           const uint64_t *__restrict__ in_off,
+                                                           const uint32_t *__restrict__ order,
+                                                           const uint64_t *__restrict__ out_off,
+                                                           uint8_t *__restrict__ out, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const uint32_t src = order[k];
+    const uint64_t b = in_off[src], e = in_off[src + 1];
+    uint64_t w = out_off[k];
+    for (uint64_t p0 = b; p0 < e; p0 += 64) {
+        const uint64_t p = p0 + lane;
+        const uint8_t ch = p < e ? in[p] : 0;
+        const bool ok = is_letter(ch);
+        const unsigned long long m = __ballot(ok);
+        if (ok) out[w + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)kAa2Idx_dev[(ch & 0xDF) - 'A'];
+        w += __popcll(m);
+    }
+}
 
 // ----------------------------------------------------------------------------------------
 // words: encode all k-mers of a sequence, sort them in LDS (bitonic), collapse runs
@@ -165,11 +214,20 @@ __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t 
 // ----------------------------------------------------------------------------------------
 // count: short-word counting filter, counters for the whole batch staged in LDS
 // ----------------------------------------------------------------------------------------
-// MODE 0: table entries are representatives created before this sweep (rep index =
-//         position in rep_seq); every batch query is compared.
-// MODE 1: table entries are batch members still without a representative (list `ulist`);
-//         only later queries are compared, and a query that already has a phase-A hit keeps
-//         only candidates whose key could beat it (smaller shared word code).
+// One workgroup per table entry (a representative). Keys order candidates as the
+// sequential rule does: (smallest shared word code, representative created earlier first);
+// packed as  minc << 32 | is_new << 31 | index  so that a 64-bit min picks the winner.
+//   MODE_TABLE  table = representatives that existed before this sweep (index = rep index);
+//               every batch query is compared.
+//   MODE_NEW    table = representatives confirmed during this sweep (index = sequence index);
+//               only later queries, not yet final ones (`done`), and only candidates whose
+//               key can still beat the query's current best.
+//   MODE_BLOCK  table = the current block of still-unassigned members; only later members of
+//               the same block are compared (the block is then resolved in order on the host).
+enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2 };
+constexpr unsigned long long kNoBest = ~0ull;
+constexpr uint32_t kNewBit = 0x80000000u;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *__restrict__ table,
                                                    const uint32_t *__restrict__ d_ntable,
@@ -177,7 +235,8 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                                                    const uint32_t *__restrict__ bi_off,
                                                    const uint32_t *__restrict__ bi_ent,
                                                    const int32_t *__restrict__ req_aan,
-                                                   const unsigned long long *__restrict__ best_old,
+                                                   const unsigned long long *__restrict__ best,
+                                                   const uint8_t *__restrict__ qflag,
                                                    Pair *__restrict__ pairs, uint32_t *__restrict__ n_pairs,
                                                    uint32_t pair_cap,
                                                    unsigned long long *__restrict__ visits) {
@@ -200,44 +259,80 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
             for (uint32_t e = lo; e < hi; ++e) {
                 const uint32_t ent = bi_ent[e];
                 const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
-                if (MODE == 1 && b0 + q <= k) continue;
+                if (MODE != MODE_TABLE && b0 + q <= k) continue;  // only queries after the representative
                 atomicAdd(&cnt[q], m < mq ? m : mq);
                 atomicMin(&minc[q], code);
                 ++my_visits;
             }
         }
-        if (my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
+        if (MODE != MODE_BLOCK && my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
         __syncthreads();
         for (uint32_t q = threadIdx.x; q < nb; q += 256) {
             const uint32_t c = cnt[q];
             if (c == 0u || (int32_t)c < req_aan[b0 + q]) continue;
-            if (MODE == 1) {
-                const unsigned long long bo = best_old[q];
-                if (bo != ~0ull && minc[q] >= (uint32_t)(bo >> 32)) continue;
+            if (MODE == MODE_NEW) {
+                if (qflag[q]) continue;  // resolved inside a block already
+                const unsigned long long bo = best[q];
+                if (bo != kNoBest && minc[q] >= (uint32_t)(bo >> 32)) continue;
             }
+            if (MODE == MODE_BLOCK && !qflag[q]) continue;  // not in the current block
             const uint32_t slot = atomicAdd(n_pairs, 1u);
             if (slot < pair_cap) {
                 Pair p;
-                p.q = b0 + q; p.r = MODE == 0 ? r : k; p.cnt = c; p.minc = minc[q];
+                p.q = b0 + q; p.r = MODE == MODE_TABLE ? r : k; p.cnt = c; p.minc = minc[q];
                 p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
                 pairs[slot] = p;
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            if (MODE == 0) { if (wg_visits) atomicAdd(visits, wg_visits); }
-            else visits[k - b0] = wg_visits;
-        }
+        if (MODE != MODE_BLOCK && threadIdx.x == 0 && wg_visits) atomicAdd(visits, wg_visits);
     }
 }
 
-__global__ __launch_bounds__(256) void compact_unassigned_kernel(const unsigned long long *__restrict__ best_old,
-                                                                uint32_t b0, uint32_t nb,
-                                                                uint32_t *__restrict__ ulist,
-                                                                uint32_t *__restrict__ n_u) {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q < nb && best_old[q] == ~0ull) ulist[atomicAdd(n_u, 1u)] = b0 + q;
+// Pick the next block: the first `block_cap` batch members, in order, that are not final
+// (`done`) and have no accepted representative yet. One workgroup of 1024 threads, 4
+// consecutive members per thread, ordered by an exclusive scan.
+// counters[0] = block size, counters[1] = number of such members in total.
+__global__ __launch_bounds__(1024) void select_block_kernel(const unsigned long long *__restrict__ best,
+                                                           uint8_t *__restrict__ done,
+                                                           uint8_t *__restrict__ inblk, uint32_t b0,
+                                                           uint32_t nb, uint32_t block_cap,
+                                                           uint32_t *__restrict__ blk_list,
+                                                           uint32_t *__restrict__ counters) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    bool cand[4];
+    uint32_t c = 0;
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t q = tid * 4 + t;
+        if (q < nb && inblk[q]) { done[q] = 1; inblk[q] = 0; }  // retire the previous block
+        cand[t] = q < nb && !done[q] && best[q] == kNoBest;
+        c += cand[t];
+    }
+    part[tid] = c;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t rank = part[tid] - c;
+    for (int t = 0; t < 4; ++t) {
+        if (!cand[t]) continue;
+        if (rank < block_cap) { blk_list[rank] = b0 + tid * 4 + t; inblk[tid * 4 + t] = 1; }
+        ++rank;
+    }
+    if (tid == 1023) { counters[0] = part[tid] < block_cap ? part[tid] : block_cap; counters[1] = part[tid]; }
 }
+
+// block members are final once the host has walked the block
+__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nb && inblk[q]) { done[q] = 1; inblk[q] = 0; }
+}
+
+__global__ void snapshot_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) { *dst = *src; }
 
 // ----------------------------------------------------------------------------------------
 // diag: 2-mer diagonal histogram + best band (one wave per pair)
@@ -296,6 +391,7 @@ __device__ void band_from_histogram(DiagPtr d, int len1, int len2, int band_widt
 // rep_seq == nullptr: p.r is already a sequence index (phase B)
 __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
                                                  Pair *__restrict__ pairs,
+                                                 const uint32_t *__restrict__ d_begin,
                                                  const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
                                                  const int32_t *__restrict__ req_aa1,
                                                  const int32_t *__restrict__ req_aas, int band_width,
@@ -308,8 +404,9 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
     const uint32_t lane = threadIdx.x;
     uint32_t np = *d_npairs;
     if (np > pair_cap) np = pair_cap;
+    const uint32_t p_begin = d_begin ? *d_begin : 0u;
     constexpr int N2 = kNAA1 * kNAA1;
-    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
+    for (uint32_t p = p_begin + blockIdx.x; p < np; p += gridDim.x) {
         const Pair pr = pairs[p];
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
         const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
@@ -438,29 +535,26 @@ __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__
     return __shfl(id, end_lane);
 }
 
-// list == nullptr: align every pair with F_DIAG_PASS|F_BAND_OK (phase A) and fold accepted
-// ones into best_old[q - b0] = min(minc << 32 | rep index). list != nullptr: align the listed
-// pairs (phase B rounds) and write (iden, accepted) to out[w].
+// Aligns pairs [*d_begin, *d_npairs) that passed the diagonal test. With `best` given, an
+// accepted pair is folded into best[q - b0] = min(minc << 32 | key_flag | p.r): the
+// 64-bit minimum is the first accepted candidate in the sequential order.
 __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
                                                    Pair *__restrict__ pairs,
+                                                   const uint32_t *__restrict__ d_begin,
                                                    const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
-                                                   const uint32_t *__restrict__ list, uint32_t n_list,
                                                    const int32_t *__restrict__ req_aa1, double cluster_thd,
-                                                   uint32_t b0, unsigned long long *__restrict__ best_old,
-                                                   int2 *__restrict__ out) {
+                                                   uint32_t b0, unsigned long long *__restrict__ best,
+                                                   uint32_t key_flag) {
     __shared__ int8_t sub[kNAA1 * kNAA1];
     for (int c = threadIdx.x; c < kNAA1 * kNAA1; c += 256) sub[c] = kBlosum62_dev[c];
     __syncthreads();
-    uint32_t n = list ? n_list : *d_npairs;
-    if (!list && n > pair_cap) n = pair_cap;
+    uint32_t n = *d_npairs;
+    if (n > pair_cap) n = pair_cap;
+    const uint32_t p_begin = d_begin ? *d_begin : 0u;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (uint32_t w = blockIdx.x * 4 + wave; w < n; w += gridDim.x * 4) {
-        const uint32_t p = list ? list[w] : w;
+    for (uint32_t p = p_begin + blockIdx.x * 4 + wave; p < n; p += gridDim.x * 4) {
         const Pair pr = pairs[p];
-        if ((pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG)) != (F_DIAG_PASS | F_BAND_OK)) {
-            if (list && lane == 0) out[w] = make_int2(0, 0);
-            continue;
-        }
+        if ((pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG)) != (F_DIAG_PASS | F_BAND_OK)) continue;
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
         const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
         const int iden = band_align_wave(S.res + S.off[k1], S.res + S.off[k2], len1, len2, pr.band_left,
@@ -472,9 +566,10 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
         }
         if (lane == 0) {
             pairs[p].iden = iden;
-            if (ok) pairs[p].flags = pr.flags | F_ACCEPT;
-            if (list) out[w] = make_int2(iden, ok ? 1 : 0);
-            else if (ok) atomicMin(&best_old[k1 - b0], ((unsigned long long)pr.minc << 32) | pr.r);
+            if (ok) {
+                pairs[p].flags = pr.flags | F_ACCEPT;
+                if (best) atomicMin(&best[k1 - b0], ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
+            }
         }
     }
 }
@@ -500,14 +595,6 @@ struct Pinned {  // page-locked host staging buffer
     }
 };
 
-struct Edge {            // phase-B candidate of one query, in key order
-    uint32_t u;          // sorted sequence index of the in-batch candidate representative
-    uint32_t minc;
-    uint32_t pidx;       // index into pairsB
-    int32_t iden;
-    uint8_t aligned, accepted;
-};
-
 enum : uint8_t { ST_OPEN = 0, ST_MEMBER = 1, ST_REP = 2 };
 
 #define LAUNCH_CHECK() PGX_HIP(hipGetLastError())
@@ -524,12 +611,13 @@ int launch_words(pgx_ctx *ctx, hipStream_t st, const uint8_t *res, const uint64_
 
 }  // namespace
 
-extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const uint64_t *offsets,
-                                  uint32_t n_in, const pgx_cluster_params *P, int32_t *out_cluster,
-                                  int32_t *out_member, float *out_identity, uint8_t *out_strand,
-                                  uint32_t *out_n_clusters, pgx_cluster_stats *stats) {
+extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_offsets,
+                                      uint32_t n_in, uint64_t total_in, const pgx_cluster_params *P,
+                                      int32_t *out_cluster, int32_t *out_member, float *out_identity,
+                                      uint8_t *out_strand, uint32_t *out_n_clusters,
+                                      pgx_cluster_stats *stats, void *stream_) {
     PGX_REQUIRE(ctx && P, "NULL argument");
-    PGX_REQUIRE(n_in == 0 || (residues && offsets), "NULL sequence arrays");
+    PGX_REQUIRE(n_in == 0 || (d_residues && d_offsets), "NULL sequence arrays");
     PGX_REQUIRE(out_cluster && out_member && out_identity, "NULL output arrays");
     PGX_REQUIRE(P->alphabet == 0, "only protein rules (cd-hit) are implemented; nucleotide (cd-hit-est) is not");
     PGX_REQUIRE(P->word_len >= 2 && P->word_len <= kMaxWordLen, "word_len must be 2..5");
@@ -537,25 +625,31 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     PGX_REQUIRE(P->band_width >= 1 && P->band_width <= kMaxBand, "band_width must be 1..64");
     PGX_REQUIRE(P->min_length >= P->word_len - 1, "min_length must be at least word_len - 1");
     PGX_HIP(hipSetDevice(ctx->device_id));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = (hipStream_t)stream_;
     pgx_cluster_stats S{};
     S.n_input = n_in;
-
-    // ---- A.2 / A.3 on the host: letters -> indices, stable descending-length order --------
-    std::vector<uint32_t> in_len(n_in);
-    uint32_t max_len = 0;
+    if (out_n_clusters) *out_n_clusters = 0;
     for (uint32_t i = 0; i < n_in; ++i) {
-        PGX_REQUIRE(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing");
-        uint32_t L = 0;
-        for (uint64_t p = offsets[i]; p < offsets[i + 1]; ++p) {
-            const uint8_t ch = residues[p] & 0xDF;  // fold case
-            L += (ch >= 'A' && ch <= 'Z');
-        }
-        in_len[i] = L;
-        if (L > max_len) max_len = L;
         out_cluster[i] = -1; out_member[i] = -1; out_identity[i] = 0.f;
         if (out_strand) out_strand[i] = 0;
     }
+    if (n_in == 0) { if (stats) *stats = S; return PGX_OK; }
+
+    // ---- A.2 / A.3: letters -> indices, stable descending-length order ---------------------
+    // The GPU counts letters and later gathers/encodes the residues; the O(n) bookkeeping
+    // (counting sort by length, offsets, thresholds) is done on the host from the lengths.
+    DevBuf d_in_len;
+    PGX_HIP(d_in_len.alloc((size_t)n_in * 4));
+    {
+        ProfScope prof(ctx, "seq_len_kernel", st);
+        seq_len_kernel<<<(n_in + 3) / 4, 256, 0, st>>>(d_residues, d_offsets, n_in, d_in_len.as<uint32_t>());
+    }
+    LAUNCH_CHECK();
+    std::vector<uint32_t> in_len(n_in);
+    PGX_HIP(hipMemcpyAsync(in_len.data(), d_in_len.p, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
+    PGX_HIP(hipStreamSynchronize(st));
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n_in; ++i) max_len = std::max(max_len, in_len[i]);
     if (max_len > kMaxLen) {
         pgx_set_error("pgx_cluster_greedy: sequence of %u residues exceeds the supported maximum %u", max_len, kMaxLen);
         return PGX_ERR_CAPACITY;
@@ -568,7 +662,6 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n_in; ++i)
         if ((int)in_len[i] > P->min_length) order[bucket[max_len - in_len[i]]++] = i;
-    if (out_n_clusters) *out_n_clusters = 0;
     if (n == 0) { if (stats) *stats = S; return PGX_OK; }
 
     std::vector<uint64_t> h_off((size_t)n + 1);
@@ -576,15 +669,6 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     h_off[0] = 0;
     for (uint32_t k = 0; k < n; ++k) { h_len[k] = in_len[order[k]]; h_off[k + 1] = h_off[k] + h_len[k]; }
     const uint64_t total = h_off[n];
-    Pinned<uint8_t> h_res;
-    PGX_HIP(h_res.reserve(total));
-    for (uint32_t k = 0; k < n; ++k) {
-        uint8_t *dst = h_res.p + h_off[k];
-        for (uint64_t p = offsets[order[k]]; p < offsets[order[k] + 1]; ++p) {
-            const uint8_t ch = residues[p] & 0xDF;
-            if (ch >= 'A' && ch <= 'Z') *dst++ = (uint8_t)kAa2Idx[ch - 'A'];
-        }
-    }
     // per-query thresholds in double, exactly as the sequential rule computes them
     std::vector<int32_t> h_aa1(n), h_aas(n), h_aan(n);
     for (uint32_t k = 0; k < n; ++k) {
@@ -606,6 +690,7 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     uint32_t n_codes = 1;
     for (int t = 0; t < P->word_len; ++t) n_codes *= kNAA1;
     const uint32_t pair_cap = 4u << 20;
+    const uint32_t pair_cap_k = kBlockCap * kBlockCap / 2 + 16;  // every pair of one block
     uint64_t max_batch_words = 0;
     for (uint32_t b0 = 0; b0 < n; b0 += kBatchCap) {
         const uint32_t b1 = std::min(n, b0 + kBatchCap);
@@ -616,8 +701,8 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     const uint32_t gs_stride = 3u * (kMaxLen + 1);
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
-        d_bi_fill, d_bi_ent, d_best_old, d_ulist, d_counters, d_visits, d_pv, d_pairsA, d_pairsB, d_list, d_out,
-        d_scan_tmp, d_gscratch;
+        d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
+        d_flags, d_scan_tmp, d_gscratch, d_order;
     PGX_HIP(d_res.alloc(total + 16));
     PGX_HIP(d_off.alloc(((size_t)n + 1) * 8));
     PGX_HIP(d_len.alloc((size_t)n * 4));
@@ -633,23 +718,30 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     PGX_HIP(d_bi_fill.alloc((size_t)n_codes * 4));
     PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
     PGX_HIP(d_best_old.alloc(kBatchCap * 8));
-    PGX_HIP(d_ulist.alloc(kBatchCap * 4));
-    PGX_HIP(d_counters.alloc(16));
+    PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
+    PGX_HIP(d_new_list.alloc(kBatchCap * 4));
+    PGX_HIP(d_flags.alloc(2 * kBatchCap));
+    PGX_HIP(d_counters.alloc(32));
     PGX_HIP(d_visits.alloc(8));
-    PGX_HIP(d_pv.alloc(kBatchCap * 8));
     PGX_HIP(d_pairsA.alloc((size_t)pair_cap * sizeof(Pair)));
-    PGX_HIP(d_pairsB.alloc((size_t)pair_cap * sizeof(Pair)));
-    PGX_HIP(d_list.alloc(kBatchCap * 4));
-    PGX_HIP(d_out.alloc(kBatchCap * sizeof(int2)));
+    PGX_HIP(d_pairsN.alloc((size_t)pair_cap * sizeof(Pair)));
+    PGX_HIP(d_pairsK.alloc((size_t)pair_cap_k * sizeof(Pair)));
     if (need_gscratch) PGX_HIP(d_gscratch.alloc((size_t)diag_grid * gs_stride * 4));
     size_t scan_bytes = 0;
     PGX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(),
                                              (int)(n_codes + 1), st));
     PGX_HIP(d_scan_tmp.alloc(scan_bytes));
 
-    PGX_HIP(hipMemcpyAsync(d_res.p, h_res.p, total, hipMemcpyHostToDevice, st));
+    PGX_HIP(d_order.alloc((size_t)n * 4));
+    PGX_HIP(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     PGX_HIP(hipMemcpyAsync(d_off.p, h_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
     PGX_HIP(hipMemcpyAsync(d_len.p, h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    {
+        ProfScope prof(ctx, "encode_gather_kernel", st);
+        encode_gather_kernel<<<(n + 3) / 4, 256, 0, st>>>(d_residues, d_offsets, d_order.as<uint32_t>(),
+                                                          d_off.as<uint64_t>(), d_res.as<uint8_t>(), n);
+    }
+    LAUNCH_CHECK();
     PGX_HIP(hipMemcpyAsync(d_aa1.p, h_aa1.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     PGX_HIP(hipMemcpyAsync(d_aas.p, h_aas.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     PGX_HIP(hipMemcpyAsync(d_aan.p, h_aan.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -682,19 +774,17 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     std::vector<uint32_t> rep_seq;            // representative index -> sorted sequence index
     std::vector<int32_t> cluster_of(n, -1);   // sorted sequence index -> cluster
     std::vector<int32_t> iden_of(n, -1);      // identical residues against the representative, -1 = is one
-    Pinned<Pair> hA, hB;
-    Pinned<unsigned long long> h_best, h_pv;
-    Pinned<uint32_t> h_cnt, h_list;
-    Pinned<int2> h_out;
-    PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_pv.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(4));
-    PGX_HIP(h_list.reserve(kBatchCap)); PGX_HIP(h_out.reserve(kBatchCap));
-    uint32_t *d_nA = d_counters.as<uint32_t>(), *d_nB = d_nA + 1, *d_nU = d_nA + 2;
-    uint64_t visits_inbatch = 0;
-    std::vector<std::vector<Edge>> E(kBatchCap);
-    std::vector<uint8_t> status(kBatchCap);
-    std::vector<uint32_t> cursor(kBatchCap), member_of(kBatchCap), winner_minc(kBatchCap), order_idx;
-    std::vector<int32_t> old_iden(kBatchCap);
-    std::vector<uint8_t> won_new(kBatchCap);
+    Pinned<Pair> hA, hN, hK;
+    Pinned<unsigned long long> h_best;
+    Pinned<uint32_t> h_cnt, h_blk;
+    PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(8)); PGX_HIP(h_blk.reserve(kBatchCap));
+    // device counters: [0] pairsA, [1] pairsN, [2] pairsK, [3] pairsN range start, [4] block size, [5] open members
+    uint32_t *d_nA = d_counters.as<uint32_t>(), *d_nN = d_nA + 1, *d_nK = d_nA + 2, *d_nN0 = d_nA + 3,
+             *d_blk = d_nA + 4;
+    unsigned long long *d_best = d_best_old.as<unsigned long long>();
+    uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + kBatchCap;
+    std::vector<uint8_t> status(kBatchCap), won_new(kBatchCap);
+    std::vector<uint32_t> member_of(kBatchCap), winner_minc(kBatchCap), new_reps, order_k;
 
     for (uint32_t b0 = 0; b0 < n; b0 += kBatchCap) {
         const uint32_t nb = std::min(kBatchCap, n - b0);
@@ -703,9 +793,9 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
         // index over the batch
         PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));
         PGX_HIP(hipMemsetAsync(d_bi_fill.p, 0, (size_t)n_codes * 4, st));
-        PGX_HIP(hipMemsetAsync(d_counters.p, 0, 16, st));
-        PGX_HIP(hipMemsetAsync(d_best_old.p, 0xFF, kBatchCap * 8, st));
-        PGX_HIP(hipMemsetAsync(d_pv.p, 0, kBatchCap * 8, st));
+        PGX_HIP(hipMemsetAsync(d_counters.p, 0, 32, st));
+        PGX_HIP(hipMemsetAsync(d_best, 0xFF, kBatchCap * 8, st));
+        PGX_HIP(hipMemsetAsync(d_done, 0, 2 * kBatchCap, st));
         {
             ProfScope prof(ctx, "index_hist_kernel", st);
             index_hist_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_cnt.as<uint32_t>());
@@ -722,175 +812,208 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
                                                      d_bi_fill.as<uint32_t>(), d_bi_ent.as<uint32_t>());
         }
         LAUNCH_CHECK();
-        // phase A: against the representatives that exist already
+        // phase A: against the representatives that exist already (fully on the device)
         if (n_reps) {
             {
                 ProfScope prof(ctx, "count_kernel<table>", st);
-                count_kernel<0><<<std::min(n_reps, 4096u), 256, 0, st>>>(
+                count_kernel<MODE_TABLE><<<std::min(n_reps, 4096u), 256, 0, st>>>(
                     DS, d_rep_seq.as<uint32_t>(), nullptr, n_reps, b0, nb, d_bi_off.as<uint32_t>(),
-                    d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, d_pairsA.as<Pair>(), d_nA, pair_cap,
-                    d_visits.as<unsigned long long>());
+                    d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, nullptr, d_pairsA.as<Pair>(), d_nA,
+                    pair_cap, d_visits.as<unsigned long long>());
             }
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "diag_kernel", st);
-                diag_kernel<<<diag_grid, 64, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), d_nA,
+                diag_kernel<<<diag_grid, 64, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), nullptr, d_nA,
                                                       pair_cap, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
                                                       P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride);
             }
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "align_kernel", st);
-                align_kernel<<<align_grid, 256, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), d_nA,
-                                                         pair_cap, nullptr, 0, d_aa1.as<int32_t>(), P->identity, b0,
-                                                         d_best_old.as<unsigned long long>(), nullptr);
+                align_kernel<<<align_grid, 256, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), nullptr,
+                                                         d_nA, pair_cap, d_aa1.as<int32_t>(), P->identity, b0, d_best, 0u);
             }
             LAUNCH_CHECK();
         }
-        // phase B: against the batch's own members that found no representative
-        compact_unassigned_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best_old.as<unsigned long long>(), b0, nb,
-                                                                    d_ulist.as<uint32_t>(), d_nU);
-        LAUNCH_CHECK();
-        {
-            ProfScope prof(ctx, "count_kernel<batch>", st);
-            count_kernel<1><<<std::min(nb, 4096u), 256, 0, st>>>(
-                DS, d_ulist.as<uint32_t>(), d_nU, 0, b0, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
-                d_aan.as<int32_t>(), d_best_old.as<unsigned long long>(), d_pairsB.as<Pair>(), d_nB, pair_cap,
-                d_pv.as<unsigned long long>());
-        }
-        LAUNCH_CHECK();
-        {
-            ProfScope prof(ctx, "diag_kernel", st);
-            diag_kernel<<<diag_grid, 64, 0, st>>>(DS, nullptr, d_pairsB.as<Pair>(), d_nB, pair_cap,
-                                                  d_aa1.as<int32_t>(), d_aas.as<int32_t>(), P->band_width,
-                                                  P->identity, d_gscratch.as<uint32_t>(), gs_stride);
-        }
-        LAUNCH_CHECK();
-        PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 16, hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipStreamSynchronize(st));
-        const uint32_t nA = h_cnt.p[0], nB = h_cnt.p[1];
-        if (nA > pair_cap || nB > pair_cap) {
-            pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u > %u) in sweep at %u",
-                          nA, nB, pair_cap, b0);
-            return PGX_ERR_CAPACITY;
-        }
-        PGX_HIP(hA.reserve(nA)); PGX_HIP(hB.reserve(nB));
-        if (nA) PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
-        if (nB) PGX_HIP(hipMemcpyAsync(hB.p, d_pairsB.p, (size_t)nB * sizeof(Pair), hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipMemcpyAsync(h_best.p, d_best_old.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipMemcpyAsync(h_pv.p, d_pv.p, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipStreamSynchronize(st));
-
-        // ---- in-order resolution on the host ---------------------------------------------
-        for (uint32_t q = 0; q < nb; ++q) { E[q].clear(); status[q] = ST_OPEN; cursor[q] = 0; old_iden[q] = -1; won_new[q] = 0; }
-        for (uint32_t i = 0; i < nA; ++i) {
-            const Pair &p = hA.p[i];
-            if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) {
-                pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
-                return PGX_ERR_CAPACITY;
-            }
-            if ((p.flags & F_ACCEPT) && (((unsigned long long)p.minc << 32) | p.r) == h_best.p[p.q - b0])
-                old_iden[p.q - b0] = p.iden;
-        }
-        for (uint32_t i = 0; i < nB; ++i) {
-            const Pair &p = hB.p[i];
-            if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) {
-                pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
-                return PGX_ERR_CAPACITY;
-            }
-            if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK))
-                E[p.q - b0].push_back(Edge{p.r, p.minc, i, 0, 0, 0});
-        }
-        for (uint32_t q = 0; q < nb; ++q)
-            std::sort(E[q].begin(), E[q].end(), [](const Edge &a, const Edge &b) {
-                return a.minc != b.minc ? a.minc < b.minc : a.u < b.u;
-            });
-        std::vector<std::pair<uint32_t, uint32_t>> flight;  // (query, edge position) of the listed pairs
+        // phase B: members without a representative, one block at a time. A block is
+        // resolved exactly (all its in-block pairs are aligned, then the host walks it in
+        // order); every later query is then compared with the block's NEW representatives
+        // only, so pair work stays close to what the one-by-one pass would do.
+        for (uint32_t q = 0; q < nb; ++q) status[q] = ST_OPEN;
+        uint32_t nN_host_checked = 0;
         for (;;) {
-            flight.clear();
-            uint32_t open = 0;
-            for (uint32_t q = 0; q < nb; ++q) {
-                if (status[q] != ST_OPEN) continue;
-                const bool has_old = h_best.p[q] != ~0ull;
-                const uint32_t old_minc = (uint32_t)(h_best.p[q] >> 32);
-                bool pending = false, joined = false;
-                while (cursor[q] < E[q].size()) {
-                    Edge &e = E[q][cursor[q]];
-                    if (has_old && e.minc >= old_minc) break;  // the phase-A hit comes first from here on
-                    const uint8_t su = status[e.u - b0];
-                    if (su == ST_MEMBER) { cursor[q]++; continue; }
-                    if (su == ST_REP) {
-                        if (!e.aligned) { flight.emplace_back(q, cursor[q]); pending = true; break; }
-                        if (e.accepted) { joined = true; break; }
-                        cursor[q]++; continue;
-                    }
-                    pending = true; break;  // candidate not decided yet
-                }
-                if (pending) { open++; continue; }
-                if (joined) {
-                    const Edge &e = E[q][cursor[q]];
-                    status[q] = ST_MEMBER; member_of[q] = e.u; won_new[q] = 1; winner_minc[q] = e.minc;
-                    iden_of[b0 + q] = e.iden;
-                } else if (has_old) {
-                    status[q] = ST_MEMBER; member_of[q] = (uint32_t)(h_best.p[q] & 0xFFFFFFFFull); won_new[q] = 0;
-                    winner_minc[q] = old_minc; iden_of[b0 + q] = old_iden[q];
-                } else {
-                    status[q] = ST_REP;
-                }
+            select_block_kernel<<<1, 1024, 0, st>>>(d_best, d_done, d_inblk, b0, nb, kBlockCap,
+                                                    d_blk_list.as<uint32_t>(), d_blk);
+            LAUNCH_CHECK();
+            PGX_HIP(hipMemsetAsync(d_nK, 0, 4, st));
+            {
+                ProfScope prof(ctx, "count_kernel<block>", st);
+                count_kernel<MODE_BLOCK><<<kBlockCap, 256, 0, st>>>(
+                    DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
+                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr);
             }
-            if (!open) break;
-            if (flight.empty()) { pgx_set_error("pgx_cluster_greedy: resolution made no progress"); return PGX_ERR_INTERNAL; }
-            const uint32_t nl = (uint32_t)flight.size();
-            for (uint32_t w = 0; w < nl; ++w) h_list.p[w] = E[flight[w].first][flight[w].second].pidx;
-            PGX_HIP(hipMemcpyAsync(d_list.p, h_list.p, (size_t)nl * 4, hipMemcpyHostToDevice, st));
+            LAUNCH_CHECK();
+            {
+                ProfScope prof(ctx, "diag_kernel", st);
+                diag_kernel<<<diag_grid, 64, 0, st>>>(DS, nullptr, d_pairsK.as<Pair>(), nullptr, d_nK, pair_cap_k,
+                                                      d_aa1.as<int32_t>(), d_aas.as<int32_t>(), P->band_width,
+                                                      P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+            }
+            LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "align_kernel", st);
-                align_kernel<<<std::min(align_grid, (nl + 3) / 4), 256, 0, st>>>(
-                    DS, nullptr, d_pairsB.as<Pair>(), d_nB, pair_cap, d_list.as<uint32_t>(), nl, d_aa1.as<int32_t>(),
-                    P->identity, b0, nullptr, d_out.as<int2>());
+                align_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsK.as<Pair>(), nullptr, d_nK, pair_cap_k,
+                                                         d_aa1.as<int32_t>(), P->identity, b0, nullptr, 0u);
             }
             LAUNCH_CHECK();
-            PGX_HIP(hipMemcpyAsync(h_out.p, d_out.p, (size_t)nl * sizeof(int2), hipMemcpyDeviceToHost, st));
+            PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
             PGX_HIP(hipStreamSynchronize(st));
-            for (uint32_t w = 0; w < nl; ++w) {
-                Edge &e = E[flight[w].first][flight[w].second];
-                e.aligned = 1; e.iden = h_out.p[w].x; e.accepted = (uint8_t)h_out.p[w].y;
+            const uint32_t n_blk = h_cnt.p[4], n_open = h_cnt.p[5], nK = h_cnt.p[2];
+            if (h_cnt.p[0] > pair_cap || h_cnt.p[1] > pair_cap || nK > pair_cap_k) {
+                pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u / %u) in sweep at %u",
+                              h_cnt.p[0], h_cnt.p[1], nK, b0);
+                return PGX_ERR_CAPACITY;
             }
+            (void)nN_host_checked;
+            if (n_blk == 0) break;
+            PGX_HIP(hK.reserve(nK));
+            if (nK) PGX_HIP(hipMemcpyAsync(hK.p, d_pairsK.p, (size_t)nK * sizeof(Pair), hipMemcpyDeviceToHost, st));
+            PGX_HIP(hipMemcpyAsync(h_blk.p, d_blk_list.p, (size_t)n_blk * 4, hipMemcpyDeviceToHost, st));
+            PGX_HIP(hipStreamSynchronize(st));
+            // resolve the block in order: first accepted in-block representative by (minc, index)
+            order_k.resize(nK);
+            for (uint32_t i = 0; i < nK; ++i) order_k[i] = i;
+            std::sort(order_k.begin(), order_k.end(), [&](uint32_t x, uint32_t y) {
+                const Pair &a = hK.p[x], &c = hK.p[y];
+                if (a.q != c.q) return a.q < c.q;
+                if (a.minc != c.minc) return a.minc < c.minc;
+                return a.r < c.r;
+            });
+            new_reps.clear();
+            uint32_t pos = 0;
+            for (uint32_t t = 0; t < n_blk; ++t) {
+                const uint32_t k = h_blk.p[t], q = k - b0;
+                while (pos < nK && hK.p[order_k[pos]].q < k) ++pos;
+                bool joined = false;
+                uint32_t e = pos;
+                for (; e < nK && hK.p[order_k[e]].q == k; ++e) {
+                    const Pair &pr = hK.p[order_k[e]];
+                    if ((pr.flags & F_TOO_BIG) && (pr.flags & F_DIAG_PASS)) {
+                        pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
+                        return PGX_ERR_CAPACITY;
+                    }
+                    if (status[pr.r - b0] != ST_REP) continue;  // candidate is itself a member
+                    S.filter_pairs++;
+                    if ((pr.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
+                        S.aligned_pairs++;
+                        S.aligned_rep_len += h_len[pr.r];
+                        S.dp_cells += (uint64_t)h_len[k] * (uint64_t)(pr.band_right - pr.band_left + 1);
+                    }
+                    if (pr.flags & F_ACCEPT) {
+                        status[q] = ST_MEMBER; member_of[q] = pr.r; won_new[q] = 1; winner_minc[q] = pr.minc;
+                        iden_of[k] = pr.iden;
+                        joined = true;
+                        break;
+                    }
+                }
+                if (!joined) { status[q] = ST_REP; new_reps.push_back(k); }
+            }
+            // later queries against the block's new representatives (on the device)
+            if (!new_reps.empty()) {
+                const uint32_t nr = (uint32_t)new_reps.size();
+                PGX_HIP(hipMemcpyAsync(d_new_list.p, new_reps.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+                snapshot_kernel<<<1, 1, 0, st>>>(d_nN, d_nN0);
+                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb);
+                {
+                    ProfScope prof(ctx, "count_kernel<new>", st);
+                    count_kernel<MODE_NEW><<<nr, 256, 0, st>>>(
+                        DS, d_new_list.as<uint32_t>(), nullptr, nr, b0, nb, d_bi_off.as<uint32_t>(),
+                        d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done, d_pairsN.as<Pair>(), d_nN,
+                        pair_cap, d_visits.as<unsigned long long>());
+                }
+                LAUNCH_CHECK();
+                {
+                    ProfScope prof(ctx, "diag_kernel", st);
+                    diag_kernel<<<diag_grid, 64, 0, st>>>(DS, nullptr, d_pairsN.as<Pair>(), d_nN0, d_nN, pair_cap,
+                                                          d_aa1.as<int32_t>(), d_aas.as<int32_t>(), P->band_width,
+                                                          P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+                }
+                LAUNCH_CHECK();
+                {
+                    ProfScope prof(ctx, "align_kernel", st);
+                    align_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsN.as<Pair>(), d_nN0, d_nN, pair_cap,
+                                                             d_aa1.as<int32_t>(), P->identity, b0, d_best, kNewBit);
+                }
+                LAUNCH_CHECK();
+                PGX_HIP(hipStreamSynchronize(st));  // new_reps is reused by the next block
+            }
+            if (n_open == n_blk) break;  // that was the last block
         }
-        // ---- close the sweep: number the new representatives in order, statistics --------
+        // ---- close the sweep ---------------------------------------------------------------
+        PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipMemcpyAsync(h_best.p, d_best, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipStreamSynchronize(st));
+        const uint32_t nA = h_cnt.p[0], nN = h_cnt.p[1];
+        if (nA > pair_cap || nN > pair_cap) {
+            pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u > %u) in sweep at %u",
+                          nA, nN, pair_cap, b0);
+            return PGX_ERR_CAPACITY;
+        }
+        PGX_HIP(hA.reserve(nA)); PGX_HIP(hN.reserve(nN));
+        if (nA) PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        if (nN) PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)nN * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipStreamSynchronize(st));
+        // members that were never in a block: their winner is the 64-bit minimum in best[]
+        for (uint32_t q = 0; q < nb; ++q) {
+            if (status[q] != ST_OPEN) continue;
+            const unsigned long long key = h_best.p[q];
+            if (key == kNoBest) { pgx_set_error("pgx_cluster_greedy: unresolved member after the last block"); return PGX_ERR_INTERNAL; }
+            status[q] = ST_MEMBER;
+            winner_minc[q] = (uint32_t)(key >> 32);
+            won_new[q] = ((uint32_t)key & kNewBit) != 0;
+            member_of[q] = (uint32_t)key & ~kNewBit;
+        }
+        // new representatives are numbered in sequence order
         for (uint32_t q = 0; q < nb; ++q)
             if (status[q] == ST_REP) {
                 cluster_of[b0 + q] = (int32_t)rep_seq.size();
                 rep_seq.push_back(b0 + q);
                 S.sum_len_reps += h_len[b0 + q];
                 S.rep_words += h_wcnt[b0 + q];
-                visits_inbatch += h_pv.p[q];
             }
         for (uint32_t q = 0; q < nb; ++q)
             if (status[q] == ST_MEMBER)
                 cluster_of[b0 + q] = won_new[q] ? cluster_of[member_of[q]] : (int32_t)member_of[q];
-        auto tally = [&](const Pair &p, uint32_t len2) {
-            S.filter_pairs++;
-            if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
-                S.aligned_pairs++;
-                S.aligned_rep_len += len2;
-                S.dp_cells += (uint64_t)h_len[p.q] * (uint64_t)(p.band_right - p.band_left + 1);
+        // identities of the winners + the candidates the one-by-one pass would have examined
+        auto examine = [&](const Pair &p, bool is_new, uint32_t len2) {
+            const uint32_t q = p.q - b0;
+            if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) return false;
+            bool seen = status[q] == ST_REP;
+            if (!seen) {
+                if (p.minc != winner_minc[q]) seen = p.minc < winner_minc[q];
+                else if (is_new != (won_new[q] != 0)) seen = !is_new;       // older representatives first
+                else seen = p.r <= member_of[q];
             }
+            if (seen) {
+                S.filter_pairs++;
+                if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
+                    S.aligned_pairs++;
+                    S.aligned_rep_len += len2;
+                    S.dp_cells += (uint64_t)h_len[p.q] * (uint64_t)(p.band_right - p.band_left + 1);
+                }
+                if ((p.flags & F_ACCEPT) && status[q] == ST_MEMBER && p.minc == winner_minc[q] &&
+                    is_new == (won_new[q] != 0) && p.r == member_of[q])
+                    iden_of[p.q] = p.iden;
+            }
+            return true;
         };
-        for (uint32_t i = 0; i < nA; ++i) {  // candidates the one-by-one pass would have examined
-            const Pair &p = hA.p[i];
-            const uint32_t q = p.q - b0;
-            bool seen = status[q] == ST_REP;
-            if (!seen) seen = p.minc < winner_minc[q] || (p.minc == winner_minc[q] && (won_new[q] || p.r <= member_of[q]));
-            if (seen) tally(p, h_len[rep_seq[p.r]]);
-        }
-        for (uint32_t i = 0; i < nB; ++i) {
-            const Pair &p = hB.p[i];
-            const uint32_t q = p.q - b0;
-            if (status[p.r - b0] != ST_REP) continue;
-            bool seen = status[q] == ST_REP;
-            if (!seen) seen = p.minc < winner_minc[q] || (p.minc == winner_minc[q] && won_new[q] && p.r <= member_of[q]);
-            if (seen) tally(p, h_len[p.r]);
+        bool fits = true;
+        for (uint32_t i = 0; i < nA; ++i) fits &= examine(hA.p[i], false, h_len[rep_seq[hA.p[i].r]]);
+        for (uint32_t i = 0; i < nN; ++i) fits &= examine(hN.p[i], true, h_len[hN.p[i].r]);
+        if (!fits) {
+            pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
+            return PGX_ERR_CAPACITY;
         }
         if (rep_seq.size() > n_reps)
             PGX_HIP(hipMemcpyAsync(d_rep_seq.as<uint32_t>() + n_reps, rep_seq.data() + n_reps,
@@ -901,7 +1024,7 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     unsigned long long visits_table = 0;
     PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
-    S.posting_visits = visits_table + visits_inbatch;
+    S.posting_visits = visits_table;
     S.n_clusters = rep_seq.size();
 
     // ---- outputs in the caller's order; member numbers follow the sorted order (A.3) ------
@@ -916,4 +1039,24 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     if (out_n_clusters) *out_n_clusters = (uint32_t)rep_seq.size();
     if (stats) *stats = S;
     return PGX_OK;
+}
+
+extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const uint64_t *offsets,
+                                  uint32_t n_in, const pgx_cluster_params *P, int32_t *out_cluster,
+                                  int32_t *out_member, float *out_identity, uint8_t *out_strand,
+                                  uint32_t *out_n_clusters, pgx_cluster_stats *stats) {
+    PGX_REQUIRE(ctx && P, "NULL argument");
+    PGX_REQUIRE(n_in == 0 || (residues && offsets), "NULL sequence arrays");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    for (uint32_t i = 0; i < n_in; ++i) PGX_REQUIRE(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing");
+    const uint64_t total_in = n_in ? offsets[n_in] : 0;
+    DevBuf d_res, d_off;
+    PGX_HIP(d_res.alloc(total_in + 16));
+    PGX_HIP(d_off.alloc(((size_t)n_in + 1) * 8));
+    if (n_in) {
+        PGX_HIP(hipMemcpyAsync(d_res.p, residues, total_in, hipMemcpyHostToDevice, ctx->stream));
+        PGX_HIP(hipMemcpyAsync(d_off.p, offsets, ((size_t)n_in + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return pgx_cluster_greedy_dev(ctx, d_res.as<uint8_t>(), d_off.as<uint64_t>(), n_in, total_in, P, out_cluster,
+                                  out_member, out_identity, out_strand, out_n_clusters, stats, ctx->stream);
 }

@@ -9,6 +9,7 @@ a 5 % tier substitutes 15-25 % (straddles the 0.8 threshold), and 1 % of the rec
 """
 
 import os
+import sys
 
 import numpy as np
 
@@ -92,7 +93,7 @@ class ProteinSet(object):
                     chunks.append(s)
                     lens.append(len(s))
             if progress and (g + 1) % progress == 0:
-                print('  synth: genome %d / %d, %d non-redundant' % (g + 1, self.n_genomes, len(lens)), flush=True)
+                print('  synth: genome %d / %d, %d non-redundant' % (g + 1, self.n_genomes, len(lens)), file=sys.stderr, flush=True)
         offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
         np.cumsum(np.asarray(lens, dtype=np.uint64), out=offsets[1:])
         residues = np.frombuffer(b''.join(chunks), dtype=np.uint8)
