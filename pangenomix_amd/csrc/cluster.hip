@@ -535,6 +535,161 @@ __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__
     return __shfl(id, end_lane);
 }
 
+// ----------------------------------------------------------------------------------------
+// align16: the same recurrence for the common case (band <= 32 diagonals, len1 + len2 <=
+// kA16MaxSum), four pairs per wave.
+//
+//   * one pair per DPP row of 16 lanes; lane g owns band columns 2g and 2g+1, so every lane
+//     computes one cell on every step of the anti-diagonal wavefront (no idle parity) and
+//     needs ONE neighbour exchange per step: row_shr:1 before the even column (left cell,
+//     from lane g-1's odd column), row_shl:1 before the odd column (top cell, from lane
+//     g+1's even column); everything else is the lane's own previous cells.
+//   * scores are int32: S * 2^14 + E with S the BLOSUM/gap sum and E the centre-diagonal
+//     bonus total (E <= 4 * min(len) < 2^14), which orders and ties exactly like the
+//     reference's 655360 * S + E.
+//   * both sequences are staged in LDS (aligned dword copies); substitution score + bonus
+//     come from four LDS tables (bonus 1..4), looked up one row ahead of use.
+//   * border cells (row 0 / column 0 of the DP matrix) are produced by the same lanes as
+//     forced values, so interior cells never special-case their neighbours.
+// ----------------------------------------------------------------------------------------
+constexpr int kA16Slot = 4096;     // LDS bytes per pair
+constexpr int kA16MaxSum = 4000;   // len1 + len2 handled by the fast path
+constexpr int kScaleShift = 14;
+
+__device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_row_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
+
+__device__ __forceinline__ bool pair_is_wide(int len1, int len2, int bl, int br) {
+    return len1 + len2 > kA16MaxSum || br - bl + 1 > 32;
+}
+
+__global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
+                                                     Pair *__restrict__ pairs,
+                                                     const uint32_t *__restrict__ d_begin,
+                                                     const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
+                                                     const int32_t *__restrict__ req_aa1, double cluster_thd,
+                                                     uint32_t b0, unsigned long long *__restrict__ best,
+                                                     uint32_t key_flag) {
+    __shared__ int32_t tab[4][kNAA1 * kNAA1];
+    __shared__ uint32_t seqbuf[16][kA16Slot / 4];
+    for (int c = threadIdx.x; c < 4 * kNAA1 * kNAA1; c += 256) {
+        const int s = kBlosum62_dev[c % (kNAA1 * kNAA1)];
+        tab[c / (kNAA1 * kNAA1)][c % (kNAA1 * kNAA1)] = s * (1 << kScaleShift) + (s > 0 ? c / (kNAA1 * kNAA1) + 1 : 0);
+    }
+    __syncthreads();
+    uint32_t n = *d_npairs;
+    if (n > pair_cap) n = pair_cap;
+    const uint32_t p_begin = d_begin ? *d_begin : 0u;
+    const int lane = threadIdx.x & 63, gl = lane & 15;
+    const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(seqbuf[slot]);
+    const int gap = kGapOpen * (1 << kScaleShift), ext = kGapExt * (1 << kScaleShift);
+    constexpr int kNever = INT32_MIN / 2;
+
+    for (uint32_t base = p_begin + blockIdx.x * 16u; base < n; base += gridDim.x * 16u) {
+        const uint32_t p = base + (uint32_t)slot;
+        Pair pr{};
+        bool fast = false;
+        int len1 = 1, len2 = 1;
+        uint32_t k1 = 0, k2 = 0;
+        if (p < n) {
+            pr = pairs[p];
+            k1 = pr.q; k2 = rep_seq ? rep_seq[pr.r] : pr.r;
+            len1 = (int)S.len[k1]; len2 = (int)S.len[k2];
+            fast = (pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG)) == (F_DIAG_PASS | F_BAND_OK) &&
+                   !pair_is_wide(len1, len2, pr.band_left, pr.band_right);
+        }
+        const int bl = pr.band_left, bw = fast ? pr.band_right - pr.band_left + 1 : 0;
+        // ---- stage both sequences (aligned dword copies keep the source misalignment) ----
+        int o1 = 0, o2 = 0;
+        if (fast) {
+            const uint8_t *g1 = S.res + S.off[k1], *g2 = S.res + S.off[k2];
+            const int a1 = (int)((uintptr_t)g1 & 3u), a2 = (int)((uintptr_t)g2 & 3u);
+            const int w1 = (len1 + a1 + 3) >> 2, w2 = (len2 + a2 + 3) >> 2;
+            const uint32_t *q1 = reinterpret_cast<const uint32_t *>(g1 - a1);
+            const uint32_t *q2 = reinterpret_cast<const uint32_t *>(g2 - a2);
+            for (int w = gl; w < w1; w += 16) seqbuf[slot][w] = q1[w];
+            for (int w = gl; w < w2; w += 16) seqbuf[slot][w1 + w] = q2[w];
+            o1 = a1; o2 = 4 * w1 + a2;
+        }
+        // ---- per-lane geometry of its two band columns -------------------------------------
+        const int c0 = 2 * gl, c1 = c0 + 1;
+        const bool v0 = c0 < bw, v1 = c1 < bw;
+        const int if0 = max(0, -bl - c0), if1 = max(0, -bl - c1);          // border row of the column
+        const int ie0 = min(len1, len2 - bl - c0), ie1 = min(len1, len2 - bl - c1);
+        const int bs0 = ext * (if0 > 0 ? if0 : c0 + bl), bs1 = ext * (if1 > 0 ? if1 : c1 + bl);
+        const int maxd = pr.band_center - bl;
+        const int d0 = c0 > maxd ? c0 - maxd : maxd - c0, d1 = c1 > maxd ? c1 - maxd : maxd - c1;
+        const int32_t *t0 = tab[3 - (d0 & 3)], *t1 = tab[3 - (d1 & 3)];   // bonus = 4 - (dist & 3)
+        const bool left0 = c0 > 0, top0 = c0 + 1 < bw, top1 = c1 + 1 < bw;
+        const int trip = fast ? len1 + ((bw + 1) >> 1) : 0;                // rows 0..len1 for lanes 0..nl-1
+
+        // residues / table entries are fetched one row ahead
+        auto res1 = [&](int i) { return (int)sb[o1 + max(i - 1, 0)]; };       // query residue of row i
+        auto res2 = [&](int j) { return (int)sb[o2 + min(max(j - 1, 0), len2 - 1)]; };  // representative residue of column j
+        int i = -gl;                                 // row of this lane in iteration tau: i = tau - gl
+        int ci = res1(i), cje = res2(c0 + i + bl), cjo = res2(c1 + i + bl);
+        int se = t0[ci * kNAA1 + cje], so = t1[ci * kNAA1 + cjo];
+        int me = ci == cje, mo = ci == cjo;
+        int sc0 = 0, m0 = 0, sc1 = 0, m1 = 0;       // last cell of the even / odd column: score, iden << 2 | back
+        for (int tau = 0; __any(tau < trip); ++tau, ++i) {
+            // next row's operands
+            const int ci_n = res1(i + 1), cjo_n = res2(c1 + i + 1 + bl);
+            const int cje_n = cjo;                   // j_even(tau + 1) == j_odd(tau)
+            const int se_n = t0[ci_n * kNAA1 + cje_n], so_n = t1[ci_n * kNAA1 + cjo_n];
+            const int l_sc = dpp_row_shr1(sc1), l_m = dpp_row_shr1(m1);
+            // ---- even column: cell (i, c0) ----
+            {
+                const bool act = v0 && tau < trip && i >= if0 && i <= ie0;
+                const int g0 = i == ie0 ? ext : gap;
+                int bst = sc0 + se, bm = ((m0 >> 2) + me) << 2 | BK_DIAG;
+                const int ls = left0 ? l_sc + ((l_m & 3) == BK_LEFT ? ext : g0) : kNever;
+                if (ls > bst) { bst = ls; bm = (l_m & ~3) | BK_LEFT; }
+                const int ts = top0 ? sc1 + ((m1 & 3) == BK_TOP ? ext : g0) : kNever;
+                if (ts > bst) { bst = ts; bm = (m1 & ~3) | BK_TOP; }
+                if (i == if0) { bst = bs0; bm = BK_NONE; }
+                if (act) { sc0 = bst; m0 = bm; }
+            }
+            const int r_sc = dpp_row_shl1(sc0), r_m = dpp_row_shl1(m0);
+            // ---- odd column: cell (i, c1) ----
+            {
+                const bool act = v1 && tau < trip && i >= if1 && i <= ie1;
+                const int g0 = i == ie1 ? ext : gap;
+                int bst = sc1 + so, bm = ((m1 >> 2) + mo) << 2 | BK_DIAG;
+                const int ls = sc0 + ((m0 & 3) == BK_LEFT ? ext : g0);
+                if (ls > bst) { bst = ls; bm = (m0 & ~3) | BK_LEFT; }
+                const int ts = top1 ? r_sc + ((r_m & 3) == BK_TOP ? ext : g0) : kNever;
+                if (ts > bst) { bst = ts; bm = (r_m & ~3) | BK_TOP; }
+                if (i == if1) { bst = bs1; bm = BK_NONE; }
+                if (act) { sc1 = bst; m1 = bm; }
+            }
+            cje = cje_n; cjo = cjo_n; ci = ci_n; se = se_n; so = so_n;
+            me = ci == cje; mo = ci == cjo;
+        }
+        // ---- end cell = last cell of its column (see band_align_wave) ----------------------
+        int ce;
+        if (len2 - bl < len1) ce = 0;
+        else if (len1 + pr.band_right < len2) ce = bw - 1;
+        else ce = len2 - len1 - bl;
+        ce = max(ce, 0);
+        const int src = (lane & 48) + (ce >> 1);
+        const int e0 = __shfl(m0, src), e1 = __shfl(m1, src);
+        const int iden = ((ce & 1) ? e1 : e0) >> 2;
+        if (fast && gl == 0) {
+            bool ok = iden >= req_aa1[k1];
+            if (ok) {
+                const float pc = (float)iden / (float)len1;
+                ok = !((double)pc < cluster_thd);
+            }
+            pairs[p].iden = iden;
+            if (ok) {
+                pairs[p].flags = pr.flags | F_ACCEPT;
+                if (best) atomicMin(&best[k1 - b0], ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
+            }
+        }
+    }
+}
+
 // Aligns pairs [*d_begin, *d_npairs) that passed the diagonal test. With `best` given, an
 // accepted pair is folded into best[q - b0] = min(minc << 32 | key_flag | p.r): the
 // 64-bit minimum is the first accepted candidate in the sequential order.
@@ -544,7 +699,7 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
                                                    const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
                                                    const int32_t *__restrict__ req_aa1, double cluster_thd,
                                                    uint32_t b0, unsigned long long *__restrict__ best,
-                                                   uint32_t key_flag) {
+                                                   uint32_t key_flag, int wide_only) {
     __shared__ int8_t sub[kNAA1 * kNAA1];
     for (int c = threadIdx.x; c < kNAA1 * kNAA1; c += 256) sub[c] = kBlosum62_dev[c];
     __syncthreads();
@@ -557,6 +712,7 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
         if ((pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG)) != (F_DIAG_PASS | F_BAND_OK)) continue;
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
         const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
+        if (wide_only && !pair_is_wide(len1, len2, pr.band_left, pr.band_right)) continue;
         const int iden = band_align_wave(S.res + S.off[k1], S.res + S.off[k2], len1, len2, pr.band_left,
                                          pr.band_center, pr.band_right, sub);
         bool ok = iden >= req_aa1[k1];
@@ -790,6 +946,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         const uint32_t nb = std::min(kBatchCap, n - b0);
         const uint32_t n_reps = (uint32_t)rep_seq.size();
         S.sweeps++;
+        // the general (int64, one pair per wave) aligner is only needed when some pair of this
+        // sweep cannot use the 16-lane fast path: query length + longest sequence, or the band
+        const bool any_wide = P->band_width > 32 || (int)(h_len[b0] + max_len) > kA16MaxSum;
         // index over the batch
         PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));
         PGX_HIP(hipMemsetAsync(d_bi_fill.p, 0, (size_t)n_codes * 4, st));
@@ -831,8 +990,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "align_kernel", st);
-                align_kernel<<<align_grid, 256, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), nullptr,
-                                                         d_nA, pair_cap, d_aa1.as<int32_t>(), P->identity, b0, d_best, 0u);
+                align16_kernel<<<align_grid, 256, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), nullptr,
+                                                           d_nA, pair_cap, d_aa1.as<int32_t>(), P->identity, b0, d_best, 0u);
+                if (any_wide)
+                    align_kernel<<<align_grid, 256, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), nullptr,
+                                                             d_nA, pair_cap, d_aa1.as<int32_t>(), P->identity, b0, d_best, 0u, 1);
             }
             LAUNCH_CHECK();
         }
@@ -863,8 +1025,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "align_kernel", st);
-                align_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsK.as<Pair>(), nullptr, d_nK, pair_cap_k,
-                                                         d_aa1.as<int32_t>(), P->identity, b0, nullptr, 0u);
+                align16_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsK.as<Pair>(), nullptr, d_nK, pair_cap_k,
+                                                           d_aa1.as<int32_t>(), P->identity, b0, nullptr, 0u);
+                if (any_wide)
+                    align_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsK.as<Pair>(), nullptr, d_nK, pair_cap_k,
+                                                             d_aa1.as<int32_t>(), P->identity, b0, nullptr, 0u, 1);
             }
             LAUNCH_CHECK();
             PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
@@ -942,8 +1107,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 LAUNCH_CHECK();
                 {
                     ProfScope prof(ctx, "align_kernel", st);
-                    align_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsN.as<Pair>(), d_nN0, d_nN, pair_cap,
-                                                             d_aa1.as<int32_t>(), P->identity, b0, d_best, kNewBit);
+                    align16_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsN.as<Pair>(), d_nN0, d_nN, pair_cap,
+                                                               d_aa1.as<int32_t>(), P->identity, b0, d_best, kNewBit);
+                    if (any_wide)
+                        align_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsN.as<Pair>(), d_nN0, d_nN, pair_cap,
+                                                                 d_aa1.as<int32_t>(), P->identity, b0, d_best, kNewBit, 1);
                 }
                 LAUNCH_CHECK();
                 PGX_HIP(hipStreamSynchronize(st));  // new_reps is reused by the next block
