@@ -29,6 +29,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 
@@ -43,7 +45,7 @@ constexpr uint32_t kBatchCap = 4096;   // queries per sweep = LDS counters per w
 constexpr uint32_t kBlockCap = 512;    // unassigned members resolved together inside a sweep
 constexpr uint32_t kMaxLen = 32767;    // longest supported sequence
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
-constexpr uint32_t kDiagLdsCap = 4096;  // diagonals kept in LDS by the diag kernel
+constexpr uint32_t kDiagLdsCap = 2048;  // diagonals / query 2-mers kept in LDS by the diag kernel
 constexpr int kMaxBand = 64;
 
 __constant__ int8_t kBlosum62_dev[kNAA1 * kNAA1] = PGXC_BLOSUM62_FLAT;
@@ -377,12 +379,14 @@ __device__ void band_from_histogram(DiagPtr d, int len1, int len2, int band_widt
     int mlen = imax;
     if (imax > len1) mlen = nall - imax;
     const int emax = (int)((1.0 - cluster_thd) * mlen) + 1;
+    // (a window without a single hit leaves imax = 0 and trims below band_b: those diagonals
+    // are not stored; such a pair fails the test whatever they hold because required_aas >= 1)
     for (int j = from; j < imax; ++j) {
         const int s1 = (int)(d[j] & 0xFFFFu);
         if ((imax - j) > emax || s1 < 1) { best_score -= s1; from++; } else break;
     }
     for (int j = end; j > imax; --j) {
-        const int s1 = (int)(d[j] & 0xFFFFu);
+        const int s1 = j >= band_b ? (int)(d[j] & 0xFFFFu) : 0;
         if ((j - imax) > emax || s1 < 1) { best_score -= s1; end--; } else break;
     }
     *bl = from - len1 + 1; *br = end - len1 + 1; *bc = imax - len1 + 1; *best_sum = best_score;
@@ -413,11 +417,16 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
         const uint8_t *s1 = S.res + S.off[k1];
         const uint8_t *s2 = S.res + S.off[k2];
         const int nall = len1 + len2 - 1;
-        const bool big = (uint32_t)nall > kDiagLdsCap || (uint32_t)len1 > kDiagLdsCap;
+        // only diagonals with an overlap of at least required_aa1 residues are ever read back
+        // (band_b .. band_e of the sequential rule), so only that window is histogrammed
+        const int d_lo = req_aa1[k1] - 1 >= 0 ? req_aa1[k1] - 1 : 0;
+        const int d_hi = nall - d_lo;
+        const int n_d = d_hi >= d_lo ? d_hi - d_lo + 1 : 0;
+        const bool big = (uint32_t)n_d > kDiagLdsCap || (uint32_t)len1 > kDiagLdsCap;
         uint32_t *dg = big ? gscratch + (size_t)blockIdx.x * gscratch_stride : diag;
         // the query's 2-mer position lists (global scratch tail for oversized queries)
         uint32_t *al_big = big ? dg + 2 * (kMaxLen + 1) : nullptr;
-        for (int i = lane; i < nall; i += 64) dg[i] = 0u;
+        for (int i = lane; i < n_d; i += 64) dg[i] = 0u;
         for (int c = lane; c < N2; c += 64) taap[c] = 0u;
         __syncthreads();
         for (int j = lane; j < len1 - 1; j += 64) atomicAdd(&taap[s1[j] * kNAA1 + s1[j + 1]], 1u);
@@ -441,14 +450,15 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
             const uint32_t b = abeg[c], e = b + taap[c];
             for (uint32_t t = b; t < e; ++t) {
                 const int j = big ? (int)al_big[t] : (int)alist[t];
-                atomicAdd(&dg[len1 - 1 + i - j], inc);
+                const int d = len1 - 1 + i - j;
+                if (d >= d_lo && d <= d_hi) atomicAdd(&dg[d - d_lo], inc);
             }
         }
         __syncthreads();
         if (lane == 0) {
             int best_sum, bl, bc, br;
             const int bw = band_width < len1 + len2 - 2 ? band_width : len1 + len2 - 2;
-            band_from_histogram(dg, len1, len2, bw, req_aa1[k1], cluster_thd, &best_sum, &bl, &bc, &br);
+            band_from_histogram(dg - d_lo, len1, len2, bw, req_aa1[k1], cluster_thd, &best_sum, &bl, &bc, &br);
             uint32_t fl = 0;
             if (best_sum >= req_aas[k1]) fl |= F_DIAG_PASS;
             if (!(br >= len2 || bl <= -len1 || bl > br)) fl |= F_BAND_OK;
@@ -755,6 +765,18 @@ enum : uint8_t { ST_OPEN = 0, ST_MEMBER = 1, ST_REP = 2 };
 
 #define LAUNCH_CHECK() PGX_HIP(hipGetLastError())
 
+// The sweep loop waits on the stream thousands of times for a few tens of microseconds;
+// polling returns as soon as the queue drains instead of after an interrupt wake-up.
+static double g_wait_s = 0.0;  // host time spent waiting for the stream (PGX_TRACE)
+static inline hipError_t spin_sync(hipStream_t st) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e;
+    while ((e = hipStreamQuery(st)) == hipErrorNotReady) {
+    }
+    g_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return e;
+}
+
 template <int NCAP, int THREADS>
 int launch_words(pgx_ctx *ctx, hipStream_t st, const uint8_t *res, const uint64_t *off, const uint32_t *len,
                  uint32_t k0, uint32_t k1, int word_len, uint32_t *wcode, uint16_t *wmult, uint32_t *wcnt) {
@@ -839,6 +861,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             h_aan[k] = (int)(P->aan_cutoff * (double)len);
         }
         S.sum_len_queries += (uint64_t)len;
+        PGX_REQUIRE(h_aas[k] >= 1, "aas_cutoff too small: every sequence needs required_aas >= 1");
     }
     S.n_clustered = n;
 
@@ -933,15 +956,25 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     Pinned<Pair> hA, hN, hK;
     Pinned<unsigned long long> h_best;
     Pinned<uint32_t> h_cnt, h_blk;
+    Pinned<uint32_t> h_new, h_rep_stage[2];
+    PGX_HIP(h_rep_stage[0].reserve(kBatchCap)); PGX_HIP(h_rep_stage[1].reserve(kBatchCap));
+    constexpr uint32_t kPrefix = 4096;  // pairs copied back together with the counters
     PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(8)); PGX_HIP(h_blk.reserve(kBatchCap));
+    PGX_HIP(h_new.reserve(kBatchCap)); PGX_HIP(hK.reserve(pair_cap_k)); PGX_HIP(hA.reserve(kPrefix)); PGX_HIP(hN.reserve(kPrefix));
     // device counters: [0] pairsA, [1] pairsN, [2] pairsK, [3] pairsN range start, [4] block size, [5] open members
     uint32_t *d_nA = d_counters.as<uint32_t>(), *d_nN = d_nA + 1, *d_nK = d_nA + 2, *d_nN0 = d_nA + 3,
              *d_blk = d_nA + 4;
     unsigned long long *d_best = d_best_old.as<unsigned long long>();
     uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + kBatchCap;
     std::vector<uint8_t> status(kBatchCap), won_new(kBatchCap);
-    std::vector<uint32_t> member_of(kBatchCap), winner_minc(kBatchCap), new_reps, order_k;
+    std::vector<uint32_t> member_of(kBatchCap), winner_minc(kBatchCap), new_reps, order_k, rank_of(kBatchCap),
+        bucket_k(kBlockCap + 2), fill_k(kBlockCap + 2);
 
+    const bool trace = std::getenv("PGX_TRACE") != nullptr;
+    const auto t_loop0 = std::chrono::steady_clock::now();
+    double t_resolve = 0.0, t_close = 0.0;
+    uint64_t n_blocks = 0;
+    g_wait_s = 0.0;
     for (uint32_t b0 = 0; b0 < n; b0 += kBatchCap) {
         const uint32_t nb = std::min(kBatchCap, n - b0);
         const uint32_t n_reps = (uint32_t)rep_seq.size();
@@ -1003,7 +1036,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // order); every later query is then compared with the block's NEW representatives
         // only, so pair work stays close to what the one-by-one pass would do.
         for (uint32_t q = 0; q < nb; ++q) status[q] = ST_OPEN;
-        uint32_t nN_host_checked = 0;
+        uint32_t new_off = 0;  // new representatives of this sweep so far (staging offset)
         for (;;) {
             select_block_kernel<<<1, 1024, 0, st>>>(d_best, d_done, d_inblk, b0, nb, kBlockCap,
                                                     d_blk_list.as<uint32_t>(), d_blk);
@@ -1032,68 +1065,84 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                                                              d_aa1.as<int32_t>(), P->identity, b0, nullptr, 0u, 1);
             }
             LAUNCH_CHECK();
+            // one round trip: counters, the block list and a prefix of the in-block pairs
             PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
-            PGX_HIP(hipStreamSynchronize(st));
+            PGX_HIP(hipMemcpyAsync(h_blk.p, d_blk_list.p, (size_t)kBlockCap * 4, hipMemcpyDeviceToHost, st));
+            PGX_HIP(hipMemcpyAsync(hK.p, d_pairsK.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
+            PGX_HIP(spin_sync(st));
             const uint32_t n_blk = h_cnt.p[4], n_open = h_cnt.p[5], nK = h_cnt.p[2];
             if (h_cnt.p[0] > pair_cap || h_cnt.p[1] > pair_cap || nK > pair_cap_k) {
                 pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u / %u) in sweep at %u",
                               h_cnt.p[0], h_cnt.p[1], nK, b0);
                 return PGX_ERR_CAPACITY;
             }
-            (void)nN_host_checked;
             if (n_blk == 0) break;
-            PGX_HIP(hK.reserve(nK));
-            if (nK) PGX_HIP(hipMemcpyAsync(hK.p, d_pairsK.p, (size_t)nK * sizeof(Pair), hipMemcpyDeviceToHost, st));
-            PGX_HIP(hipMemcpyAsync(h_blk.p, d_blk_list.p, (size_t)n_blk * 4, hipMemcpyDeviceToHost, st));
-            PGX_HIP(hipStreamSynchronize(st));
+            if (nK > kPrefix) {
+                PGX_HIP(hipMemcpyAsync(hK.p + kPrefix, d_pairsK.as<Pair>() + kPrefix, (size_t)(nK - kPrefix) * sizeof(Pair),
+                                       hipMemcpyDeviceToHost, st));
+                PGX_HIP(spin_sync(st));
+            }
             // resolve the block in order: first accepted in-block representative by (minc, index)
+            const auto t_r0 = std::chrono::steady_clock::now();
+            ++n_blocks;
+            // bucket the in-block pairs by query (counting sort on the query's rank in the block)
+            for (uint32_t t = 0; t < n_blk; ++t) { rank_of[h_blk.p[t] - b0] = t; bucket_k[t] = 0; }
+            bucket_k[n_blk] = 0;
+            for (uint32_t i = 0; i < nK; ++i) bucket_k[rank_of[hK.p[i].q - b0] + 1]++;
+            for (uint32_t t = 0; t < n_blk; ++t) bucket_k[t + 1] += bucket_k[t];   // bucket t = [bucket_k[t], bucket_k[t+1])
+            for (uint32_t t = 0; t < n_blk; ++t) fill_k[t] = bucket_k[t];
             order_k.resize(nK);
-            for (uint32_t i = 0; i < nK; ++i) order_k[i] = i;
-            std::sort(order_k.begin(), order_k.end(), [&](uint32_t x, uint32_t y) {
-                const Pair &a = hK.p[x], &c = hK.p[y];
-                if (a.q != c.q) return a.q < c.q;
-                if (a.minc != c.minc) return a.minc < c.minc;
-                return a.r < c.r;
-            });
+            for (uint32_t i = 0; i < nK; ++i) order_k[fill_k[rank_of[hK.p[i].q - b0]]++] = i;
             new_reps.clear();
-            uint32_t pos = 0;
             for (uint32_t t = 0; t < n_blk; ++t) {
                 const uint32_t k = h_blk.p[t], q = k - b0;
-                while (pos < nK && hK.p[order_k[pos]].q < k) ++pos;
-                bool joined = false;
-                uint32_t e = pos;
-                for (; e < nK && hK.p[order_k[e]].q == k; ++e) {
+                const uint32_t lo = bucket_k[t], hi = bucket_k[t + 1];
+                // winner = accepted in-block representative with the smallest (minc, index)
+                unsigned long long win = kNoBest;
+                int32_t win_iden = 0;
+                for (uint32_t e = lo; e < hi; ++e) {
                     const Pair &pr = hK.p[order_k[e]];
                     if ((pr.flags & F_TOO_BIG) && (pr.flags & F_DIAG_PASS)) {
                         pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
                         return PGX_ERR_CAPACITY;
                     }
+                    if (status[pr.r - b0] != ST_REP || !(pr.flags & F_ACCEPT)) continue;
+                    const unsigned long long key = ((unsigned long long)pr.minc << 32) | pr.r;
+                    if (key < win) { win = key; win_iden = pr.iden; }
+                }
+                // candidates the one-by-one pass examines: in-block representatives up to the winner
+                for (uint32_t e = lo; e < hi; ++e) {
+                    const Pair &pr = hK.p[order_k[e]];
                     if (status[pr.r - b0] != ST_REP) continue;  // candidate is itself a member
+                    if ((((unsigned long long)pr.minc << 32) | pr.r) > win) continue;
                     S.filter_pairs++;
                     if ((pr.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
                         S.aligned_pairs++;
                         S.aligned_rep_len += h_len[pr.r];
                         S.dp_cells += (uint64_t)h_len[k] * (uint64_t)(pr.band_right - pr.band_left + 1);
                     }
-                    if (pr.flags & F_ACCEPT) {
-                        status[q] = ST_MEMBER; member_of[q] = pr.r; won_new[q] = 1; winner_minc[q] = pr.minc;
-                        iden_of[k] = pr.iden;
-                        joined = true;
-                        break;
-                    }
                 }
-                if (!joined) { status[q] = ST_REP; new_reps.push_back(k); }
+                if (win != kNoBest) {
+                    status[q] = ST_MEMBER; member_of[q] = (uint32_t)win; won_new[q] = 1;
+                    winner_minc[q] = (uint32_t)(win >> 32); iden_of[k] = win_iden;
+                } else {
+                    status[q] = ST_REP; new_reps.push_back(k);
+                }
             }
+            t_resolve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count();
             // later queries against the block's new representatives (on the device)
             if (!new_reps.empty()) {
                 const uint32_t nr = (uint32_t)new_reps.size();
-                PGX_HIP(hipMemcpyAsync(d_new_list.p, new_reps.data(), (size_t)nr * 4, hipMemcpyHostToDevice, st));
+                uint32_t *d_new = d_new_list.as<uint32_t>() + new_off;  // every block has its own staging range
+                std::copy(new_reps.begin(), new_reps.end(), h_new.p + new_off);
+                PGX_HIP(hipMemcpyAsync(d_new, h_new.p + new_off, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+                new_off += nr;
                 snapshot_kernel<<<1, 1, 0, st>>>(d_nN, d_nN0);
                 retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb);
                 {
                     ProfScope prof(ctx, "count_kernel<new>", st);
                     count_kernel<MODE_NEW><<<nr, 256, 0, st>>>(
-                        DS, d_new_list.as<uint32_t>(), nullptr, nr, b0, nb, d_bi_off.as<uint32_t>(),
+                        DS, d_new, nullptr, nr, b0, nb, d_bi_off.as<uint32_t>(),
                         d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done, d_pairsN.as<Pair>(), d_nN,
                         pair_cap, d_visits.as<unsigned long long>());
                 }
@@ -1114,25 +1163,29 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                                                                  d_aa1.as<int32_t>(), P->identity, b0, d_best, kNewBit, 1);
                 }
                 LAUNCH_CHECK();
-                PGX_HIP(hipStreamSynchronize(st));  // new_reps is reused by the next block
             }
             if (n_open == n_blk) break;  // that was the last block
         }
         // ---- close the sweep ---------------------------------------------------------------
         PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
         PGX_HIP(hipMemcpyAsync(h_best.p, d_best, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipStreamSynchronize(st));
+        PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        PGX_HIP(spin_sync(st));
         const uint32_t nA = h_cnt.p[0], nN = h_cnt.p[1];
         if (nA > pair_cap || nN > pair_cap) {
             pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u > %u) in sweep at %u",
                           nA, nN, pair_cap, b0);
             return PGX_ERR_CAPACITY;
         }
-        PGX_HIP(hA.reserve(nA)); PGX_HIP(hN.reserve(nN));
-        if (nA) PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
-        if (nN) PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)nN * sizeof(Pair), hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipStreamSynchronize(st));
+        if (nA > kPrefix || nN > kPrefix) {
+            PGX_HIP(hA.reserve(nA)); PGX_HIP(hN.reserve(nN));  // (reserve keeps nothing: copy whole ranges again)
+            if (nA) PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
+            if (nN) PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)nN * sizeof(Pair), hipMemcpyDeviceToHost, st));
+            PGX_HIP(spin_sync(st));
+        }
         // members that were never in a block: their winner is the 64-bit minimum in best[]
+        const auto t_c0 = std::chrono::steady_clock::now();
         for (uint32_t q = 0; q < nb; ++q) {
             if (status[q] != ST_OPEN) continue;
             const unsigned long long key = h_best.p[q];
@@ -1183,11 +1236,22 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
             return PGX_ERR_CAPACITY;
         }
-        if (rep_seq.size() > n_reps)
-            PGX_HIP(hipMemcpyAsync(d_rep_seq.as<uint32_t>() + n_reps, rep_seq.data() + n_reps,
-                                   (rep_seq.size() - n_reps) * 4, hipMemcpyHostToDevice, st));
-        PGX_HIP(hipStreamSynchronize(st));  // rep_seq may reallocate before the copy is consumed
+        if (rep_seq.size() > n_reps) {
+            // staged through a pinned buffer of its own parity so the next sweep can start at once
+            uint32_t *stage = h_rep_stage[S.sweeps & 1].p;
+            std::copy(rep_seq.begin() + n_reps, rep_seq.end(), stage);
+            PGX_HIP(hipMemcpyAsync(d_rep_seq.as<uint32_t>() + n_reps, stage, (rep_seq.size() - n_reps) * 4,
+                                   hipMemcpyHostToDevice, st));
+        }
+        t_close += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
     }
+    if (trace)
+        fprintf(stderr, "[pgx] sweeps %llu blocks %llu: loop %.1f ms = wait %.1f + block resolve %.1f + sweep close %.1f + "
+                "enqueue/other %.1f\n", (unsigned long long)S.sweeps, (unsigned long long)n_blocks,
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count(), 1e3 * g_wait_s,
+                1e3 * t_resolve, 1e3 * t_close,
+                1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() - g_wait_s -
+                       t_resolve - t_close));
 
     unsigned long long visits_table = 0;
     PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
