@@ -817,6 +817,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     // The GPU counts letters and later gathers/encodes the residues; the O(n) bookkeeping
     // (counting sort by length, offsets, thresholds) is done on the host from the lengths.
     DevBuf d_in_len;
+    d_in_len.ctx = ctx; d_in_len.slot = 0;
     PGX_HIP(d_in_len.alloc((size_t)n_in * 4));
     {
         ProfScope prof(ctx, "seq_len_kernel", st);
@@ -882,6 +883,13 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
         d_flags, d_scan_tmp, d_gscratch, d_order;
+    {   // all of them live in the context's workspace (slots 1..)
+        DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
+                         &d_bi_cnt, &d_bi_off, &d_bi_fill, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
+                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order};
+        int sl = 1;
+        for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
+    }
     PGX_HIP(d_res.alloc(total + 16));
     PGX_HIP(d_off.alloc(((size_t)n + 1) * 8));
     PGX_HIP(d_len.alloc((size_t)n * 4));

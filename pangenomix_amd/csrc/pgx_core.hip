@@ -127,6 +127,8 @@ void pgx_ctx_destroy(pgx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto &a : ctx->arena)
+        if (a.first) (void)hipFree(a.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -27,6 +27,8 @@ struct pgx_ctx {
     bool profiling = false;
     std::vector<ProfSlot> prof;
     std::vector<hipEvent_t> event_pool;
+    // grow-only device workspace, reused by successive calls on this context (slot -> buffer)
+    std::vector<std::pair<void *, size_t>> arena;
 };
 
 // RAII bracket: records start/stop events on `stream` when profiling is enabled.
@@ -59,13 +61,32 @@ void pgx_set_error(const char *fmt, ...);
         }                                                                                  \
     } while (0)
 
-// RAII device buffer for the host-pointer entry points.
+// Device buffer. Stand-alone (freed on scope exit) or, when bound to a context slot, a view
+// of that slot of the context's grow-only workspace: repeated calls then neither allocate
+// nor free (hipFree of GB-sized buffers stalls the queue for milliseconds).
 struct DevBuf {
     void *p = nullptr;
+    pgx_ctx *ctx = nullptr;
+    int slot = -1;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p && !ctx) (void)hipFree(p);
     }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    hipError_t alloc(size_t bytes) {
+        if (!bytes) bytes = 16;
+        if (!ctx) return hipMalloc(&p, bytes);
+        if ((int)ctx->arena.size() <= slot) ctx->arena.resize((size_t)slot + 1, {nullptr, 0});
+        auto &a = ctx->arena[(size_t)slot];
+        if (!a.first || a.second < bytes) {
+            if (a.first) (void)hipFree(a.first);
+            a = {nullptr, 0};
+            const size_t cap = bytes + bytes / 4 + 256;
+            hipError_t e = hipMalloc(&a.first, cap);
+            if (e != hipSuccess) return e;
+            a.second = cap;
+        }
+        p = a.first;
+        return hipSuccess;
+    }
     template <typename T>
     T *as() {
         return static_cast<T *>(p);
