@@ -32,6 +32,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "cluster_tables.h"
@@ -302,11 +303,12 @@ __global__ __launch_bounds__(1024) void select_block_kernel(const unsigned long 
                                                            uint32_t *__restrict__ blk_list,
                                                            uint32_t *__restrict__ counters) {
     __shared__ uint32_t part[1024];
+    constexpr int PER = kBatchCap / 1024;
     const uint32_t tid = threadIdx.x;
-    bool cand[4];
+    bool cand[PER];
     uint32_t c = 0;
-    for (int t = 0; t < 4; ++t) {
-        const uint32_t q = tid * 4 + t;
+    for (int t = 0; t < PER; ++t) {
+        const uint32_t q = tid * PER + t;
         if (q < nb && inblk[q]) { done[q] = 1; inblk[q] = 0; }  // retire the previous block
         cand[t] = q < nb && !done[q] && best[q] == kNoBest;
         c += cand[t];
@@ -320,9 +322,9 @@ __global__ __launch_bounds__(1024) void select_block_kernel(const unsigned long 
         __syncthreads();
     }
     uint32_t rank = part[tid] - c;
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < PER; ++t) {
         if (!cand[t]) continue;
-        if (rank < block_cap) { blk_list[rank] = b0 + tid * 4 + t; inblk[tid * 4 + t] = 1; }
+        if (rank < block_cap) { blk_list[rank] = b0 + tid * PER + t; inblk[tid * PER + t] = 1; }
         ++rank;
     }
     if (tid == 1023) { counters[0] = part[tid] < block_cap ? part[tid] : block_cap; counters[1] = part[tid]; }
@@ -642,40 +644,64 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
         int se = t0[ci * kNAA1 + cje], so = t1[ci * kNAA1 + cjo];
         int me = ci == cje, mo = ci == cjo;
         int sc0 = 0, m0 = 0, sc1 = 0, m1 = 0;       // last cell of the even / odd column: score, iden << 2 | back
-        for (int tau = 0; __any(tau < trip); ++tau, ++i) {
-            // next row's operands
-            const int ci_n = res1(i + 1), cjo_n = res2(c1 + i + 1 + bl);
-            const int cje_n = cjo;                   // j_even(tau + 1) == j_odd(tau)
-            const int se_n = t0[ci_n * kNAA1 + cje_n], so_n = t1[ci_n * kNAA1 + cjo_n];
+
+        // One row of the wavefront for this lane's two columns. INTERIOR = every live column of
+        // the wave is strictly inside its row range (no border cell, no last row/column, nothing
+        // starts or ends), so all range logic drops out of the dependent chain.
+        auto row = [&](int tau, auto interior) {
+            constexpr bool INTERIOR = decltype(interior)::value;
+            const int ci_n = res1(i + 1), cjo_n = res2(c1 + i + 1 + bl);   // operands of the next row
+            const int cje_n = cjo;                                         // j_even(tau + 1) == j_odd(tau)
             const int l_sc = dpp_row_shr1(sc1), l_m = dpp_row_shr1(m1);
-            // ---- even column: cell (i, c0) ----
-            {
-                const bool act = v0 && tau < trip && i >= if0 && i <= ie0;
-                const int g0 = i == ie0 ? ext : gap;
+            {   // ---- even column: cell (i, c0) ----
+                const int g0 = INTERIOR ? gap : (i == ie0 ? ext : gap);
                 int bst = sc0 + se, bm = ((m0 >> 2) + me) << 2 | BK_DIAG;
                 const int ls = left0 ? l_sc + ((l_m & 3) == BK_LEFT ? ext : g0) : kNever;
                 if (ls > bst) { bst = ls; bm = (l_m & ~3) | BK_LEFT; }
                 const int ts = top0 ? sc1 + ((m1 & 3) == BK_TOP ? ext : g0) : kNever;
                 if (ts > bst) { bst = ts; bm = (m1 & ~3) | BK_TOP; }
-                if (i == if0) { bst = bs0; bm = BK_NONE; }
-                if (act) { sc0 = bst; m0 = bm; }
+                if (INTERIOR) { if (v0) { sc0 = bst; m0 = bm; } }
+                else {
+                    if (i == if0) { bst = bs0; bm = BK_NONE; }
+                    if (v0 && tau < trip && i >= if0 && i <= ie0) { sc0 = bst; m0 = bm; }
+                }
             }
             const int r_sc = dpp_row_shl1(sc0), r_m = dpp_row_shl1(m0);
-            // ---- odd column: cell (i, c1) ----
-            {
-                const bool act = v1 && tau < trip && i >= if1 && i <= ie1;
-                const int g0 = i == ie1 ? ext : gap;
+            {   // ---- odd column: cell (i, c1) ----
+                const int g0 = INTERIOR ? gap : (i == ie1 ? ext : gap);
                 int bst = sc1 + so, bm = ((m1 >> 2) + mo) << 2 | BK_DIAG;
                 const int ls = sc0 + ((m0 & 3) == BK_LEFT ? ext : g0);
                 if (ls > bst) { bst = ls; bm = (m0 & ~3) | BK_LEFT; }
                 const int ts = top1 ? r_sc + ((r_m & 3) == BK_TOP ? ext : g0) : kNever;
                 if (ts > bst) { bst = ts; bm = (r_m & ~3) | BK_TOP; }
-                if (i == if1) { bst = bs1; bm = BK_NONE; }
-                if (act) { sc1 = bst; m1 = bm; }
+                if (INTERIOR) { if (v1) { sc1 = bst; m1 = bm; } }
+                else {
+                    if (i == if1) { bst = bs1; bm = BK_NONE; }
+                    if (v1 && tau < trip && i >= if1 && i <= ie1) { sc1 = bst; m1 = bm; }
+                }
             }
-            cje = cje_n; cjo = cjo_n; ci = ci_n; se = se_n; so = so_n;
+            // keep the next row's table look-ups (which wait for the residues read above) behind
+            // the DP arithmetic, so the LDS latency overlaps it
+            __builtin_amdgcn_sched_barrier(0);
+            cje = cje_n; cjo = cjo_n; ci = ci_n;
+            se = t0[ci * kNAA1 + cje]; so = t1[ci * kNAA1 + cjo];
             me = ci == cje; mo = ci == cjo;
+            ++i;
+        };
+        // interior range of the wave: [lo, hi) = rows where every live lane has both cells interior
+        int lo = 0, hi = INT32_MAX, wtrip = trip;
+        if (fast && v0) {
+            lo = max(if0, v1 ? if1 : 0) + gl + 1;
+            hi = min(ie0, v1 ? ie1 : ie0) + gl;
         }
+        for (int d = 32; d > 0; d >>= 1) {
+            lo = max(lo, __shfl_xor(lo, d)); hi = min(hi, __shfl_xor(hi, d)); wtrip = max(wtrip, __shfl_xor(wtrip, d));
+        }
+        lo = min(lo, wtrip); hi = min(hi, wtrip);
+        int tau = 0;
+        for (; tau < lo; ++tau) row(tau, std::false_type{});
+        for (; tau < hi; ++tau) row(tau, std::true_type{});
+        for (; tau < wtrip; ++tau) row(tau, std::false_type{});
         // ---- end cell = last cell of its column (see band_align_wave) ----------------------
         int ce;
         if (len2 - bl < len1) ce = 0;
