@@ -48,7 +48,46 @@ def draw_permutations(num_strains, num_iter):
     return perms
 
 
-def estimate_pan_core_size(df_genes, num_iter, log_batch=-1, ctx=None):
+def shard_bounds(num_iter, rank, world):
+    """Contiguous slice [lo, hi) of the iterations that `rank` of `world` computes.
+    Iterations are independent given their permutation: no data-path collective."""
+    base, extra = divmod(num_iter, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _pan_core_sharded(ctx, bits, num_genes, perms, group, compute=None):
+    """Iterations sharded over the ranks of `group`; results gathered on every rank. The
+    bitmap is replicated (<= 10 MB at 400 genomes). `compute(bits, n_genes, perms)` defaults
+    to the GPU kernel; tests inject the oracle to rehearse the sharding on CPU (gloo)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_iter, S = perms.shape
+    lo, hi = shard_bounds(n_iter, rank, world)
+    compute = compute or ctx.pan_core
+    if hi > lo:
+        pan, core = compute(bits, num_genes, perms[lo:hi])
+    else:
+        pan = core = np.zeros((0, S), dtype=np.int32)
+    width = (n_iter + world - 1) // world                      # equal-sized slots for all_gather
+    mine = np.zeros((2, width, S), dtype=np.int32)
+    mine[0, :hi - lo], mine[1, :hi - lo] = pan, core
+    backend = dist.get_backend(group)
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    t = torch.from_numpy(mine).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    pan_all = np.empty((n_iter, S), dtype=np.int32)
+    core_all = np.empty((n_iter, S), dtype=np.int32)
+    for r in range(world):
+        a, b = shard_bounds(n_iter, r, world)
+        part = out[r].cpu().numpy()
+        pan_all[a:b], core_all[a:b] = part[0, :b - a], part[1, :b - a]
+    return pan_all, core_all
+
+
+def estimate_pan_core_size(df_genes, num_iter, log_batch=-1, ctx=None, group=None):
     """Pan/core genome size curves for `num_iter` random genome orders.
 
     df_genes : LightSparseDataFrame, binary gene x genome table
@@ -56,6 +95,10 @@ def estimate_pan_core_size(df_genes, num_iter, log_batch=-1, ctx=None):
     log_batch: accepted for compatibility (the GPU computes all iterations in one
                launch; a line is printed per batch boundary as the reference does)
     ctx      : optional pangenomix_amd._native.Context (default: process-wide)
+    group    : optional torch.distributed process group (one process per GPU). Every rank
+               draws the SAME permutations (same RNG state required, e.g. np.random.seed(k)
+               on every rank), computes its contiguous share of the iterations on its own
+               GPU, and the shares are all-gathered; every rank returns the full table.
     """
     num_genes, num_strains = df_genes.shape
     print('Converting DataFrame to matrix...')
@@ -68,7 +111,9 @@ def estimate_pan_core_size(df_genes, num_iter, log_batch=-1, ctx=None):
     if log_batch > 0:
         for i in range(log_batch, num_iter + 1, log_batch):
             print('\tIteration', i, 'of', num_iter)
-    if num_iter > 0 and num_strains > 0:
+    if group is not None and num_iter > 0 and num_strains > 0:
+        pan, core = _pan_core_sharded(ctx, bits, num_genes, perms, group)
+    elif num_iter > 0 and num_strains > 0:
         pan, core = ctx.pan_core(bits, num_genes, perms)
     else:
         pan = np.zeros((num_iter, num_strains), dtype=np.int32)
