@@ -37,7 +37,10 @@ class ClusterStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in STAT_FIELDS] + [('reserved', C.c_uint64 * 4)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n in STAT_FIELDS}
+        d = {n: int(getattr(self, n)) for n in STAT_FIELDS}
+        d['gpu'] = {'pairs': int(self.reserved[0]), 'aligned': int(self.reserved[1]),
+                    'aligned_bytes': int(self.reserved[2])}
+        return d
 
 
 # every symbol include/pgx.h declares: (restype, argtypes)

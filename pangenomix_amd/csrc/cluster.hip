@@ -191,12 +191,17 @@ __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restric
 // batch index: CSR by word code over the batch's distinct words
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void index_hist_kernel(DevSeqs S, uint32_t b0, uint32_t nb,
-                                                        uint32_t *__restrict__ bi_cnt) {
+                                                        uint32_t *__restrict__ bi_cnt,
+                                                        uint32_t *__restrict__ bi_bits) {
     const uint32_t k = b0 + blockIdx.x;
     if (blockIdx.x >= nb) return;
     const uint64_t o = S.off[k];
     const uint32_t n = S.wcnt[k];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&bi_cnt[S.wcode[o + i]], 1u);
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const uint32_t code = S.wcode[o + i];
+        atomicAdd(&bi_cnt[code], 1u);
+        atomicOr(&bi_bits[code >> 5], 1u << (code & 31u));  // presence bitmap: 512 KB, L2-resident
+    }
 }
 
 __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t b0, uint32_t nb,
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                                                    uint32_t ntable_host, uint32_t b0, uint32_t nb,
                                                    const uint32_t *__restrict__ bi_off,
                                                    const uint32_t *__restrict__ bi_ent,
+                                                   const uint32_t *__restrict__ bi_bits,
                                                    const int32_t *__restrict__ req_aan,
                                                    const unsigned long long *__restrict__ best,
                                                    const uint8_t *__restrict__ qflag,
@@ -257,6 +263,9 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
         uint32_t my_visits = 0;
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const uint32_t code = S.wcode[o + i];
+            // most of a representative's words do not occur in the batch: ask the L2-resident
+            // bitmap first and touch the 16 MB offset array only for words that do
+            if (!((bi_bits[code >> 5] >> (code & 31u)) & 1u)) continue;
             const uint32_t m = S.wmult[o + i];
             const uint32_t lo = bi_off[code], hi = bi_off[code + 1];
             for (uint32_t e = lo; e < hi; ++e) {
@@ -908,11 +917,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
-        d_flags, d_scan_tmp, d_gscratch, d_order;
+        d_flags, d_scan_tmp, d_gscratch, d_order, d_bi_bits;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
                          &d_bi_cnt, &d_bi_off, &d_bi_fill, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
-                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order};
+                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_bi_bits};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -930,6 +939,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_bi_off.alloc(((size_t)n_codes + 1) * 4));
     PGX_HIP(d_bi_fill.alloc((size_t)n_codes * 4));
     PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
+    PGX_HIP(d_bi_bits.alloc(((size_t)n_codes / 32 + 1) * 4));
     PGX_HIP(d_best_old.alloc(kBatchCap * 8));
     PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
     PGX_HIP(d_new_list.alloc(kBatchCap * 4));
@@ -1004,6 +1014,15 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     std::vector<uint32_t> member_of(kBatchCap), winner_minc(kBatchCap), new_reps, order_k, rank_of(kBatchCap),
         bucket_k(kBlockCap + 2), fill_k(kBlockCap + 2);
 
+    uint64_t gpu_pairs = 0, gpu_aligned = 0, gpu_aligned_bytes = 0;  // actual device work (reserved stats slots)
+    auto account = [&](const Pair *pp, uint32_t cnt, bool via_rep) {
+        for (uint32_t i = 0; i < cnt; ++i) {
+            ++gpu_pairs;
+            if ((pp[i].flags & (F_DIAG_PASS | F_BAND_OK)) != (F_DIAG_PASS | F_BAND_OK)) continue;
+            ++gpu_aligned;
+            gpu_aligned_bytes += h_len[pp[i].q] + h_len[via_rep ? rep_seq[pp[i].r] : pp[i].r];
+        }
+    };
     const bool trace = std::getenv("PGX_TRACE") != nullptr;
     const auto t_loop0 = std::chrono::steady_clock::now();
     double t_resolve = 0.0, t_close = 0.0;
@@ -1019,12 +1038,13 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // index over the batch
         PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));
         PGX_HIP(hipMemsetAsync(d_bi_fill.p, 0, (size_t)n_codes * 4, st));
+        PGX_HIP(hipMemsetAsync(d_bi_bits.p, 0, ((size_t)n_codes / 32 + 1) * 4, st));
         PGX_HIP(hipMemsetAsync(d_counters.p, 0, 32, st));
         PGX_HIP(hipMemsetAsync(d_best, 0xFF, kBatchCap * 8, st));
         PGX_HIP(hipMemsetAsync(d_done, 0, 2 * kBatchCap, st));
         {
             ProfScope prof(ctx, "index_hist_kernel", st);
-            index_hist_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_cnt.as<uint32_t>());
+            index_hist_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_cnt.as<uint32_t>(), d_bi_bits.as<uint32_t>());
         }
         LAUNCH_CHECK();
         {
@@ -1044,7 +1064,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 ProfScope prof(ctx, "count_kernel<table>", st);
                 count_kernel<MODE_TABLE><<<std::min(n_reps, 4096u), 256, 0, st>>>(
                     DS, d_rep_seq.as<uint32_t>(), nullptr, n_reps, b0, nb, d_bi_off.as<uint32_t>(),
-                    d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, nullptr, d_pairsA.as<Pair>(), d_nA,
+                    d_bi_ent.as<uint32_t>(), d_bi_bits.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, nullptr, d_pairsA.as<Pair>(), d_nA,
                     pair_cap, d_visits.as<unsigned long long>());
             }
             LAUNCH_CHECK();
@@ -1080,7 +1100,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 ProfScope prof(ctx, "count_kernel<block>", st);
                 count_kernel<MODE_BLOCK><<<kBlockCap, 256, 0, st>>>(
                     DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
-                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr);
+                    d_bi_bits.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr);
             }
             LAUNCH_CHECK();
             {
@@ -1119,6 +1139,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             // resolve the block in order: first accepted in-block representative by (minc, index)
             const auto t_r0 = std::chrono::steady_clock::now();
             ++n_blocks;
+            account(hK.p, nK, false);
             // bucket the in-block pairs by query (counting sort on the query's rank in the block)
             for (uint32_t t = 0; t < n_blk; ++t) { rank_of[h_blk.p[t] - b0] = t; bucket_k[t] = 0; }
             bucket_k[n_blk] = 0;
@@ -1177,7 +1198,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                     ProfScope prof(ctx, "count_kernel<new>", st);
                     count_kernel<MODE_NEW><<<nr, 256, 0, st>>>(
                         DS, d_new, nullptr, nr, b0, nb, d_bi_off.as<uint32_t>(),
-                        d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done, d_pairsN.as<Pair>(), d_nN,
+                        d_bi_ent.as<uint32_t>(), d_bi_bits.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done, d_pairsN.as<Pair>(), d_nN,
                         pair_cap, d_visits.as<unsigned long long>());
                 }
                 LAUNCH_CHECK();
@@ -1263,6 +1284,8 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             }
             return true;
         };
+        account(hA.p, nA, true);
+        account(hN.p, nN, false);
         bool fits = true;
         for (uint32_t i = 0; i < nA; ++i) fits &= examine(hA.p[i], false, h_len[rep_seq[hA.p[i].r]]);
         for (uint32_t i = 0; i < nN; ++i) fits &= examine(hN.p[i], true, h_len[hN.p[i].r]);
@@ -1291,6 +1314,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
     S.posting_visits = visits_table;
+    S.reserved[0] = gpu_pairs; S.reserved[1] = gpu_aligned; S.reserved[2] = gpu_aligned_bytes;
     S.n_clusters = rep_seq.size();
 
     // ---- outputs in the caller's order; member numbers follow the sorted order (A.3) ------

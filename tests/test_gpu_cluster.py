@@ -17,7 +17,7 @@ def assert_same(got, want):
         assert np.array_equal(g, w), '%s differs at %s' % (name, np.flatnonzero(g != w)[:10])
     assert got[4] == want[4]
     gs, ws = dict(got[5]), dict(want[5])
-    gs.pop('sweeps'), ws.pop('sweeps')
+    gs.pop('sweeps'), ws.pop('sweeps'), gs.pop('gpu'), ws.pop('gpu')
     assert gs == ws
 
 
