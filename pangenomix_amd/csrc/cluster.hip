@@ -191,17 +191,12 @@ __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restric
 // batch index: CSR by word code over the batch's distinct words
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void index_hist_kernel(DevSeqs S, uint32_t b0, uint32_t nb,
-                                                        uint32_t *__restrict__ bi_cnt,
-                                                        uint32_t *__restrict__ bi_bits) {
+                                                        uint32_t *__restrict__ bi_cnt) {
     const uint32_t k = b0 + blockIdx.x;
     if (blockIdx.x >= nb) return;
     const uint64_t o = S.off[k];
     const uint32_t n = S.wcnt[k];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t code = S.wcode[o + i];
-        atomicAdd(&bi_cnt[code], 1u);
-        atomicOr(&bi_bits[code >> 5], 1u << (code & 31u));  // presence bitmap: 512 KB, L2-resident
-    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&bi_cnt[S.wcode[o + i]], 1u);
 }
 
 __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t b0, uint32_t nb,
@@ -242,7 +237,6 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                                                    uint32_t ntable_host, uint32_t b0, uint32_t nb,
                                                    const uint32_t *__restrict__ bi_off,
                                                    const uint32_t *__restrict__ bi_ent,
-                                                   const uint32_t *__restrict__ bi_bits,
                                                    const int32_t *__restrict__ req_aan,
                                                    const unsigned long long *__restrict__ best,
                                                    const uint8_t *__restrict__ qflag,
@@ -263,9 +257,6 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
         uint32_t my_visits = 0;
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const uint32_t code = S.wcode[o + i];
-            // most of a representative's words do not occur in the batch: ask the L2-resident
-            // bitmap first and touch the 16 MB offset array only for words that do
-            if (!((bi_bits[code >> 5] >> (code & 31u)) & 1u)) continue;
             const uint32_t m = S.wmult[o + i];
             const uint32_t lo = bi_off[code], hi = bi_off[code + 1];
             for (uint32_t e = lo; e < hi; ++e) {
@@ -917,11 +908,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
-        d_flags, d_scan_tmp, d_gscratch, d_order, d_bi_bits;
+        d_flags, d_scan_tmp, d_gscratch, d_order;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
                          &d_bi_cnt, &d_bi_off, &d_bi_fill, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
-                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_bi_bits};
+                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -939,7 +930,6 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_bi_off.alloc(((size_t)n_codes + 1) * 4));
     PGX_HIP(d_bi_fill.alloc((size_t)n_codes * 4));
     PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
-    PGX_HIP(d_bi_bits.alloc(((size_t)n_codes / 32 + 1) * 4));
     PGX_HIP(d_best_old.alloc(kBatchCap * 8));
     PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
     PGX_HIP(d_new_list.alloc(kBatchCap * 4));
@@ -1038,13 +1028,12 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // index over the batch
         PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));
         PGX_HIP(hipMemsetAsync(d_bi_fill.p, 0, (size_t)n_codes * 4, st));
-        PGX_HIP(hipMemsetAsync(d_bi_bits.p, 0, ((size_t)n_codes / 32 + 1) * 4, st));
         PGX_HIP(hipMemsetAsync(d_counters.p, 0, 32, st));
         PGX_HIP(hipMemsetAsync(d_best, 0xFF, kBatchCap * 8, st));
         PGX_HIP(hipMemsetAsync(d_done, 0, 2 * kBatchCap, st));
         {
             ProfScope prof(ctx, "index_hist_kernel", st);
-            index_hist_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_cnt.as<uint32_t>(), d_bi_bits.as<uint32_t>());
+            index_hist_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_cnt.as<uint32_t>());
         }
         LAUNCH_CHECK();
         {
@@ -1064,7 +1053,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 ProfScope prof(ctx, "count_kernel<table>", st);
                 count_kernel<MODE_TABLE><<<std::min(n_reps, 4096u), 256, 0, st>>>(
                     DS, d_rep_seq.as<uint32_t>(), nullptr, n_reps, b0, nb, d_bi_off.as<uint32_t>(),
-                    d_bi_ent.as<uint32_t>(), d_bi_bits.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, nullptr, d_pairsA.as<Pair>(), d_nA,
+                    d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, nullptr, d_pairsA.as<Pair>(), d_nA,
                     pair_cap, d_visits.as<unsigned long long>());
             }
             LAUNCH_CHECK();
@@ -1100,7 +1089,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 ProfScope prof(ctx, "count_kernel<block>", st);
                 count_kernel<MODE_BLOCK><<<kBlockCap, 256, 0, st>>>(
                     DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
-                    d_bi_bits.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr);
+                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr);
             }
             LAUNCH_CHECK();
             {
@@ -1198,7 +1187,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                     ProfScope prof(ctx, "count_kernel<new>", st);
                     count_kernel<MODE_NEW><<<nr, 256, 0, st>>>(
                         DS, d_new, nullptr, nr, b0, nb, d_bi_off.as<uint32_t>(),
-                        d_bi_ent.as<uint32_t>(), d_bi_bits.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done, d_pairsN.as<Pair>(), d_nN,
+                        d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done, d_pairsN.as<Pair>(), d_nN,
                         pair_cap, d_visits.as<unsigned long long>());
                 }
                 LAUNCH_CHECK();
