@@ -51,7 +51,7 @@ constexpr int kMaxBand = 64;
 
 __constant__ int8_t kBlosum62_dev[kNAA1 * kNAA1] = PGXC_BLOSUM62_FLAT;
 
-enum : uint32_t { F_DIAG_PASS = 1, F_BAND_OK = 2, F_ACCEPT = 4, F_TOO_BIG = 8 };
+enum : uint32_t { F_DIAG_PASS = 1, F_BAND_OK = 2, F_ACCEPT = 4, F_TOO_BIG = 8, F_EVAL = 16, F_ALIGNED = 32 };
 
 struct Pair {           // one (query, representative) candidate
     uint32_t q;         // sorted sequence index of the query
@@ -62,6 +62,29 @@ struct Pair {           // one (query, representative) candidate
     int32_t iden;
     uint32_t flags;
 };
+
+// Which pair records a diag / align launch works on: the device-side range
+// [*d_begin, min(*d_end, cap)) or an explicit list; optionally skipping pairs whose
+// candidate (a batch member, local index r - b0) has `skip_flag` set.
+struct PairSel {
+    const uint32_t *d_begin, *d_end;
+    uint32_t cap;
+    const uint32_t *list;
+    uint32_t n_list;
+    const uint8_t *skip_flag;
+    uint32_t b0;
+    uint32_t skip_evaluated;  // leave pairs alone that an earlier round has been through
+};
+__device__ __forceinline__ uint32_t sel_count(const PairSel &s) {
+    if (s.list) return s.n_list;
+    uint32_t e = *s.d_end;
+    if (e > s.cap) e = s.cap;
+    const uint32_t b = s.d_begin ? *s.d_begin : 0u;
+    return e > b ? e - b : 0u;
+}
+__device__ __forceinline__ uint32_t sel_pair(const PairSel &s, uint32_t w) {
+    return s.list ? s.list[w] : (s.d_begin ? *s.d_begin : 0u) + w;
+}
 
 struct DevSeqs {
     const uint8_t *res;     // residue indices, sorted order, concatenated
@@ -336,6 +359,42 @@ __global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restr
     if (q < nb && inblk[q]) { done[q] = 1; inblk[q] = 0; }
 }
 
+// has_cand[q - b0] = 1 for every block member that has an earlier in-block candidate; a member
+// without one (and without a representative so far) is certainly a new representative
+__global__ __launch_bounds__(256) void mark_candidates_kernel(const Pair *__restrict__ pairs,
+                                                             const uint32_t *__restrict__ d_n, uint32_t cap,
+                                                             uint32_t b0, uint8_t *__restrict__ has_cand) {
+    uint32_t n = *d_n;
+    if (n > cap) n = cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        has_cand[pairs[i].q - b0] = 1;
+}
+
+// After the first in-block round: a member that has candidates but was accepted by none of
+// the certain representatives is LIKELY a representative itself (an outlier of its family).
+// skip2[u] = 0 exactly for those, so the second round evaluates the pairs against them.
+__global__ __launch_bounds__(256) void mark_accepted_kernel(const Pair *__restrict__ pairs,
+                                                           const uint32_t *__restrict__ d_n, uint32_t cap,
+                                                           uint32_t b0, uint8_t *__restrict__ accepted) {
+    uint32_t n = *d_n;
+    if (n > cap) n = cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (pairs[i].flags & F_ACCEPT) accepted[pairs[i].q - b0] = 1;
+}
+__global__ __launch_bounds__(256) void likely_rep_kernel(const uint8_t *__restrict__ has_cand,
+                                                        const uint8_t *__restrict__ accepted, uint32_t nb,
+                                                        uint8_t *__restrict__ skip2) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nb) skip2[q] = !(has_cand[q] && !accepted[q]);
+}
+
+__global__ __launch_bounds__(256) void gather_pairs_kernel(const Pair *__restrict__ pairs,
+                                                          const uint32_t *__restrict__ list, uint32_t n,
+                                                          Pair *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pairs[list[i]];
+}
+
 __global__ void snapshot_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) { *dst = *src; }
 
 // ----------------------------------------------------------------------------------------
@@ -396,9 +455,7 @@ __device__ void band_from_histogram(DiagPtr d, int len1, int len2, int band_widt
 
 // rep_seq == nullptr: p.r is already a sequence index (phase B)
 __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
-                                                 Pair *__restrict__ pairs,
-                                                 const uint32_t *__restrict__ d_begin,
-                                                 const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
+                                                 Pair *__restrict__ pairs, PairSel sel,
                                                  const int32_t *__restrict__ req_aa1,
                                                  const int32_t *__restrict__ req_aas, int band_width,
                                                  double cluster_thd, uint32_t *__restrict__ gscratch,
@@ -408,12 +465,13 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
     __shared__ uint32_t abeg[kNAA1 * kNAA1 + 7];
     __shared__ uint16_t alist[kDiagLdsCap];
     const uint32_t lane = threadIdx.x;
-    uint32_t np = *d_npairs;
-    if (np > pair_cap) np = pair_cap;
-    const uint32_t p_begin = d_begin ? *d_begin : 0u;
+    const uint32_t np = sel_count(sel);
     constexpr int N2 = kNAA1 * kNAA1;
-    for (uint32_t p = p_begin + blockIdx.x; p < np; p += gridDim.x) {
+    for (uint32_t w = blockIdx.x; w < np; w += gridDim.x) {
+        const uint32_t p = sel_pair(sel, w);
         const Pair pr = pairs[p];
+        if (sel.skip_flag && sel.skip_flag[pr.r - sel.b0]) continue;  // block-uniform
+        if (sel.skip_evaluated && (pr.flags & F_EVAL)) continue;
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
         const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
         const uint8_t *s1 = S.res + S.off[k1];
@@ -461,7 +519,7 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
             int best_sum, bl, bc, br;
             const int bw = band_width < len1 + len2 - 2 ? band_width : len1 + len2 - 2;
             band_from_histogram(dg - d_lo, len1, len2, bw, req_aa1[k1], cluster_thd, &best_sum, &bl, &bc, &br);
-            uint32_t fl = 0;
+            uint32_t fl = F_EVAL;
             if (best_sum >= req_aas[k1]) fl |= F_DIAG_PASS;
             if (!(br >= len2 || bl <= -len1 || bl > br)) fl |= F_BAND_OK;
             if (br - bl + 1 > kMaxBand) fl |= F_TOO_BIG;
@@ -576,9 +634,7 @@ __device__ __forceinline__ bool pair_is_wide(int len1, int len2, int bl, int br)
 }
 
 __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
-                                                     Pair *__restrict__ pairs,
-                                                     const uint32_t *__restrict__ d_begin,
-                                                     const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
+                                                     Pair *__restrict__ pairs, PairSel sel,
                                                      const int32_t *__restrict__ req_aa1, double cluster_thd,
                                                      uint32_t b0, unsigned long long *__restrict__ best,
                                                      uint32_t key_flag) {
@@ -589,26 +645,26 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
         tab[c / (kNAA1 * kNAA1)][c % (kNAA1 * kNAA1)] = s * (1 << kScaleShift) + (s > 0 ? c / (kNAA1 * kNAA1) + 1 : 0);
     }
     __syncthreads();
-    uint32_t n = *d_npairs;
-    if (n > pair_cap) n = pair_cap;
-    const uint32_t p_begin = d_begin ? *d_begin : 0u;
+    const uint32_t n = sel_count(sel);
     const int lane = threadIdx.x & 63, gl = lane & 15;
     const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(seqbuf[slot]);
     const int gap = kGapOpen * (1 << kScaleShift), ext = kGapExt * (1 << kScaleShift);
     constexpr int kNever = INT32_MIN / 2;
 
-    for (uint32_t base = p_begin + blockIdx.x * 16u; base < n; base += gridDim.x * 16u) {
-        const uint32_t p = base + (uint32_t)slot;
+    for (uint32_t base = blockIdx.x * 16u; base < n; base += gridDim.x * 16u) {
+        const uint32_t w = base + (uint32_t)slot;
+        uint32_t p = 0;
         Pair pr{};
         bool fast = false;
         int len1 = 1, len2 = 1;
         uint32_t k1 = 0, k2 = 0;
-        if (p < n) {
+        if (w < n) {
+            p = sel_pair(sel, w);
             pr = pairs[p];
             k1 = pr.q; k2 = rep_seq ? rep_seq[pr.r] : pr.r;
             len1 = (int)S.len[k1]; len2 = (int)S.len[k2];
-            fast = (pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG)) == (F_DIAG_PASS | F_BAND_OK) &&
+            fast = (pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG | F_ALIGNED)) == (F_DIAG_PASS | F_BAND_OK) &&
                    !pair_is_wide(len1, len2, pr.band_left, pr.band_right);
         }
         const int bl = pr.band_left, bw = fast ? pr.band_right - pr.band_left + 1 : 0;
@@ -718,10 +774,8 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
                 ok = !((double)pc < cluster_thd);
             }
             pairs[p].iden = iden;
-            if (ok) {
-                pairs[p].flags = pr.flags | F_ACCEPT;
-                if (best) atomicMin(&best[k1 - b0], ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
-            }
+            pairs[p].flags = pr.flags | F_ALIGNED | (ok ? F_ACCEPT : 0u);
+            if (ok && best) atomicMin(&best[k1 - b0], ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
         }
     }
 }
@@ -730,22 +784,19 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
 // accepted pair is folded into best[q - b0] = min(minc << 32 | key_flag | p.r): the
 // 64-bit minimum is the first accepted candidate in the sequential order.
 __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
-                                                   Pair *__restrict__ pairs,
-                                                   const uint32_t *__restrict__ d_begin,
-                                                   const uint32_t *__restrict__ d_npairs, uint32_t pair_cap,
+                                                   Pair *__restrict__ pairs, PairSel sel,
                                                    const int32_t *__restrict__ req_aa1, double cluster_thd,
                                                    uint32_t b0, unsigned long long *__restrict__ best,
                                                    uint32_t key_flag, int wide_only) {
     __shared__ int8_t sub[kNAA1 * kNAA1];
     for (int c = threadIdx.x; c < kNAA1 * kNAA1; c += 256) sub[c] = kBlosum62_dev[c];
     __syncthreads();
-    uint32_t n = *d_npairs;
-    if (n > pair_cap) n = pair_cap;
-    const uint32_t p_begin = d_begin ? *d_begin : 0u;
+    const uint32_t n = sel_count(sel);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (uint32_t p = p_begin + blockIdx.x * 4 + wave; p < n; p += gridDim.x * 4) {
+    for (uint32_t w = blockIdx.x * 4 + wave; w < n; w += gridDim.x * 4) {
+        const uint32_t p = sel_pair(sel, w);
         const Pair pr = pairs[p];
-        if ((pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG)) != (F_DIAG_PASS | F_BAND_OK)) continue;
+        if ((pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG | F_ALIGNED)) != (F_DIAG_PASS | F_BAND_OK)) continue;
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
         const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
         if (wide_only && !pair_is_wide(len1, len2, pr.band_left, pr.band_right)) continue;
@@ -758,10 +809,8 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
         }
         if (lane == 0) {
             pairs[p].iden = iden;
-            if (ok) {
-                pairs[p].flags = pr.flags | F_ACCEPT;
-                if (best) atomicMin(&best[k1 - b0], ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
-            }
+            pairs[p].flags = pr.flags | F_ALIGNED | (ok ? F_ACCEPT : 0u);
+            if (ok && best) atomicMin(&best[k1 - b0], ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
         }
     }
 }
@@ -908,11 +957,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
-        d_flags, d_scan_tmp, d_gscratch, d_order;
+        d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
                          &d_bi_cnt, &d_bi_off, &d_bi_fill, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
-                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order};
+                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_list, &d_gather};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -933,7 +982,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_best_old.alloc(kBatchCap * 8));
     PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
     PGX_HIP(d_new_list.alloc(kBatchCap * 4));
-    PGX_HIP(d_flags.alloc(2 * kBatchCap));
+    PGX_HIP(d_flags.alloc(5 * kBatchCap));
+    PGX_HIP(d_list.alloc((size_t)pair_cap_k * 4));
+    PGX_HIP(d_gather.alloc((size_t)pair_cap_k * sizeof(Pair)));
     PGX_HIP(d_counters.alloc(32));
     PGX_HIP(d_visits.alloc(8));
     PGX_HIP(d_pairsA.alloc((size_t)pair_cap * sizeof(Pair)));
@@ -1002,7 +1053,13 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + kBatchCap;
     std::vector<uint8_t> status(kBatchCap), won_new(kBatchCap);
     std::vector<uint32_t> member_of(kBatchCap), winner_minc(kBatchCap), new_reps, order_k, rank_of(kBatchCap),
-        bucket_k(kBlockCap + 2), fill_k(kBlockCap + 2);
+        bucket_k(kBlockCap + 2), fill_k(kBlockCap + 2), flight;
+    Pinned<uint32_t> h_list;
+    Pinned<Pair> h_gather;
+    PGX_HIP(h_list.reserve(pair_cap_k)); PGX_HIP(h_gather.reserve(pair_cap_k));
+    uint8_t *d_hascand = d_flags.as<uint8_t>() + 2 * kBatchCap, *d_accepted = d_hascand + kBatchCap,
+            *d_skip2 = d_accepted + kBatchCap;
+    uint64_t n_rounds = 0;
 
     uint64_t gpu_pairs = 0, gpu_aligned = 0, gpu_aligned_bytes = 0;  // actual device work (reserved stats slots)
     auto account = [&](const Pair *pp, uint32_t cnt, bool via_rep) {
@@ -1022,6 +1079,8 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         const uint32_t nb = std::min(kBatchCap, n - b0);
         const uint32_t n_reps = (uint32_t)rep_seq.size();
         S.sweeps++;
+        const auto t_sweep0 = std::chrono::steady_clock::now();
+        const uint64_t blocks_before = n_blocks;
         // the general (int64, one pair per wave) aligner is only needed when some pair of this
         // sweep cannot use the 16-lane fast path: query length + longest sequence, or the band
         const bool any_wide = P->band_width > 32 || (int)(h_len[b0] + max_len) > kA16MaxSum;
@@ -1047,6 +1106,28 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                                                      d_bi_fill.as<uint32_t>(), d_bi_ent.as<uint32_t>());
         }
         LAUNCH_CHECK();
+        // diag + align of a selection of pair records, enqueued on the stream
+        auto evaluate = [&](const uint32_t *rep_map, Pair *pairs, const PairSel &sel, unsigned long long *best_arr,
+                            uint32_t key_flag, uint32_t grid_hint) -> int {
+            const uint32_t dg = grid_hint ? std::min(diag_grid, grid_hint) : diag_grid;
+            const uint32_t ag = grid_hint ? std::min(align_grid, (grid_hint + 15) / 16) : align_grid;
+            {
+                ProfScope prof(ctx, "diag_kernel", st);
+                diag_kernel<<<dg, 64, 0, st>>>(DS, rep_map, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
+                                               P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+            }
+            LAUNCH_CHECK();
+            {
+                ProfScope prof(ctx, "align_kernel", st);
+                align16_kernel<<<ag, 256, 0, st>>>(DS, rep_map, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0,
+                                                   best_arr, key_flag);
+                if (any_wide)
+                    align_kernel<<<grid_hint ? std::min(align_grid, (grid_hint + 3) / 4) : align_grid, 256, 0, st>>>(
+                        DS, rep_map, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, key_flag, 1);
+            }
+            LAUNCH_CHECK();
+            return PGX_OK;
+        };
         // phase A: against the representatives that exist already (fully on the device)
         if (n_reps) {
             {
@@ -1058,21 +1139,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             }
             LAUNCH_CHECK();
             {
-                ProfScope prof(ctx, "diag_kernel", st);
-                diag_kernel<<<diag_grid, 64, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), nullptr, d_nA,
-                                                      pair_cap, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
-                                                      P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+                const PairSel selA{nullptr, d_nA, pair_cap, nullptr, 0, nullptr, b0, 0};
+                int rc = evaluate(d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), selA, d_best, 0u, 0);
+                if (rc) return rc;
             }
-            LAUNCH_CHECK();
-            {
-                ProfScope prof(ctx, "align_kernel", st);
-                align16_kernel<<<align_grid, 256, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), nullptr,
-                                                           d_nA, pair_cap, d_aa1.as<int32_t>(), P->identity, b0, d_best, 0u);
-                if (any_wide)
-                    align_kernel<<<align_grid, 256, 0, st>>>(DS, d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), nullptr,
-                                                             d_nA, pair_cap, d_aa1.as<int32_t>(), P->identity, b0, d_best, 0u, 1);
-            }
-            LAUNCH_CHECK();
         }
         // phase B: members without a representative, one block at a time. A block is
         // resolved exactly (all its in-block pairs are aligned, then the host walks it in
@@ -1092,22 +1162,26 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                     d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr);
             }
             LAUNCH_CHECK();
-            {
-                ProfScope prof(ctx, "diag_kernel", st);
-                diag_kernel<<<diag_grid, 64, 0, st>>>(DS, nullptr, d_pairsK.as<Pair>(), nullptr, d_nK, pair_cap_k,
-                                                      d_aa1.as<int32_t>(), d_aas.as<int32_t>(), P->band_width,
-                                                      P->identity, d_gscratch.as<uint32_t>(), gs_stride);
-            }
+            // A block member without an earlier in-block candidate is certainly a new
+            // representative; only pairs against those are evaluated up front. Whatever the
+            // in-order walk on the host still needs afterwards goes through follow-up rounds.
+            PGX_HIP(hipMemsetAsync(d_hascand, 0, 2 * kBatchCap, st));  // has_cand + accepted
+            mark_candidates_kernel<<<256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_nK, pair_cap_k, b0, d_hascand);
             LAUNCH_CHECK();
             {
-                ProfScope prof(ctx, "align_kernel", st);
-                align16_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsK.as<Pair>(), nullptr, d_nK, pair_cap_k,
-                                                           d_aa1.as<int32_t>(), P->identity, b0, nullptr, 0u);
-                if (any_wide)
-                    align_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsK.as<Pair>(), nullptr, d_nK, pair_cap_k,
-                                                             d_aa1.as<int32_t>(), P->identity, b0, nullptr, 0u, 1);
+                const PairSel selK{nullptr, d_nK, pair_cap_k, nullptr, 0, d_hascand, b0, 0};
+                int rc = evaluate(nullptr, d_pairsK.as<Pair>(), selK, nullptr, 0u, 0);
+                if (rc) return rc;
             }
+            // second round on the device: pairs against likely (outlier) representatives
+            mark_accepted_kernel<<<256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_nK, pair_cap_k, b0, d_accepted);
+            likely_rep_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_hascand, d_accepted, nb, d_skip2);
             LAUNCH_CHECK();
+            {
+                const PairSel selK2{nullptr, d_nK, pair_cap_k, nullptr, 0, d_skip2, b0, 1};
+                int rc = evaluate(nullptr, d_pairsK.as<Pair>(), selK2, nullptr, 0u, 0);
+                if (rc) return rc;
+            }
             // one round trip: counters, the block list and a prefix of the in-block pairs
             PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
             PGX_HIP(hipMemcpyAsync(h_blk.p, d_blk_list.p, (size_t)kBlockCap * 4, hipMemcpyDeviceToHost, st));
@@ -1128,7 +1202,6 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             // resolve the block in order: first accepted in-block representative by (minc, index)
             const auto t_r0 = std::chrono::steady_clock::now();
             ++n_blocks;
-            account(hK.p, nK, false);
             // bucket the in-block pairs by query (counting sort on the query's rank in the block)
             for (uint32_t t = 0; t < n_blk; ++t) { rank_of[h_blk.p[t] - b0] = t; bucket_k[t] = 0; }
             bucket_k[n_blk] = 0;
@@ -1137,27 +1210,79 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             for (uint32_t t = 0; t < n_blk; ++t) fill_k[t] = bucket_k[t];
             order_k.resize(nK);
             for (uint32_t i = 0; i < nK; ++i) order_k[fill_k[rank_of[hK.p[i].q - b0]]++] = i;
+            // In-order walk. For member q the sequential rule takes the accepted representative
+            // with the smallest (minc, index) among its in-block candidates that ARE
+            // representatives. Pairs that neither device round evaluated and that could precede
+            // the winner are collected for ALL still-open members in one pass (candidates that
+            // are themselves undecided count as possible representatives) and evaluated in a
+            // follow-up round; the walk repeats until every member is decided.
+            uint32_t t_first = 0;
+            for (;;) {
+                flight.clear();
+                bool any_open = false;
+                for (uint32_t t = t_first; t < n_blk; ++t) {
+                    const uint32_t k = h_blk.p[t], q = k - b0;
+                    if (status[q] != ST_OPEN) continue;
+                    const uint32_t lo = bucket_k[t], hi = bucket_k[t + 1];
+                    unsigned long long win = kNoBest, open_acc = kNoBest;
+                    int32_t win_iden = 0;
+                    for (uint32_t e = lo; e < hi; ++e) {
+                        const Pair &pr = hK.p[order_k[e]];
+                        const uint8_t su = status[pr.r - b0];
+                        if (su == ST_MEMBER || !(pr.flags & F_EVAL)) continue;
+                        if ((pr.flags & F_TOO_BIG) && (pr.flags & F_DIAG_PASS)) {
+                            pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
+                            return PGX_ERR_CAPACITY;
+                        }
+                        if (!(pr.flags & F_ACCEPT)) continue;
+                        const unsigned long long key = ((unsigned long long)pr.minc << 32) | pr.r;
+                        if (su == ST_REP) { if (key < win) { win = key; win_iden = pr.iden; } }
+                        else if (key < open_acc) open_acc = key;  // wins if that member turns out a representative
+                    }
+                    bool needs = false;
+                    for (uint32_t e = lo; e < hi; ++e) {
+                        const Pair &pr = hK.p[order_k[e]];
+                        if (status[pr.r - b0] == ST_MEMBER || (pr.flags & F_EVAL)) continue;
+                        if ((((unsigned long long)pr.minc << 32) | pr.r) < win) { flight.push_back(order_k[e]); needs = true; }
+                    }
+                    if (needs || open_acc < win) { any_open = true; continue; }
+                    if (win != kNoBest) {
+                        status[q] = ST_MEMBER; member_of[q] = (uint32_t)win; won_new[q] = 1;
+                        winner_minc[q] = (uint32_t)(win >> 32); iden_of[k] = win_iden;
+                    } else {
+                        status[q] = ST_REP;
+                    }
+                }
+                if (!any_open) break;
+                while (t_first < n_blk && status[h_blk.p[t_first] - b0] != ST_OPEN) ++t_first;
+                if (flight.empty()) { pgx_set_error("pgx_cluster_greedy: block resolution made no progress"); return PGX_ERR_INTERNAL; }
+                // follow-up round: evaluate the listed pairs and fetch their records back
+                const uint32_t nl = (uint32_t)flight.size();
+                ++n_rounds;
+                std::copy(flight.begin(), flight.end(), h_list.p);
+                PGX_HIP(hipMemcpyAsync(d_list.p, h_list.p, (size_t)nl * 4, hipMemcpyHostToDevice, st));
+                {
+                    const PairSel selL{nullptr, nullptr, 0, d_list.as<uint32_t>(), nl, nullptr, b0, 0};
+                    int rc = evaluate(nullptr, d_pairsK.as<Pair>(), selL, nullptr, 0u, nl);
+                    if (rc) return rc;
+                }
+                gather_pairs_kernel<<<(nl + 255) / 256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_list.as<uint32_t>(), nl,
+                                                                      d_gather.as<Pair>());
+                LAUNCH_CHECK();
+                PGX_HIP(hipMemcpyAsync(h_gather.p, d_gather.p, (size_t)nl * sizeof(Pair), hipMemcpyDeviceToHost, st));
+                PGX_HIP(spin_sync(st));
+                for (uint32_t w = 0; w < nl; ++w) hK.p[flight[w]] = h_gather.p[w];
+            }
+            // block decided: new representatives in order + the candidates the one-by-one pass examines
             new_reps.clear();
             for (uint32_t t = 0; t < n_blk; ++t) {
                 const uint32_t k = h_blk.p[t], q = k - b0;
-                const uint32_t lo = bucket_k[t], hi = bucket_k[t + 1];
-                // winner = accepted in-block representative with the smallest (minc, index)
-                unsigned long long win = kNoBest;
-                int32_t win_iden = 0;
-                for (uint32_t e = lo; e < hi; ++e) {
+                if (status[q] == ST_REP) new_reps.push_back(k);
+                const unsigned long long win = status[q] == ST_MEMBER
+                    ? (((unsigned long long)winner_minc[q] << 32) | member_of[q]) : kNoBest;
+                for (uint32_t e = bucket_k[t]; e < bucket_k[t + 1]; ++e) {
                     const Pair &pr = hK.p[order_k[e]];
-                    if ((pr.flags & F_TOO_BIG) && (pr.flags & F_DIAG_PASS)) {
-                        pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
-                        return PGX_ERR_CAPACITY;
-                    }
-                    if (status[pr.r - b0] != ST_REP || !(pr.flags & F_ACCEPT)) continue;
-                    const unsigned long long key = ((unsigned long long)pr.minc << 32) | pr.r;
-                    if (key < win) { win = key; win_iden = pr.iden; }
-                }
-                // candidates the one-by-one pass examines: in-block representatives up to the winner
-                for (uint32_t e = lo; e < hi; ++e) {
-                    const Pair &pr = hK.p[order_k[e]];
-                    if (status[pr.r - b0] != ST_REP) continue;  // candidate is itself a member
+                    if (status[pr.r - b0] != ST_REP) continue;
                     if ((((unsigned long long)pr.minc << 32) | pr.r) > win) continue;
                     S.filter_pairs++;
                     if ((pr.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
@@ -1166,13 +1291,8 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                         S.dp_cells += (uint64_t)h_len[k] * (uint64_t)(pr.band_right - pr.band_left + 1);
                     }
                 }
-                if (win != kNoBest) {
-                    status[q] = ST_MEMBER; member_of[q] = (uint32_t)win; won_new[q] = 1;
-                    winner_minc[q] = (uint32_t)(win >> 32); iden_of[k] = win_iden;
-                } else {
-                    status[q] = ST_REP; new_reps.push_back(k);
-                }
             }
+            account(hK.p, nK, false);
             t_resolve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count();
             // later queries against the block's new representatives (on the device)
             if (!new_reps.empty()) {
@@ -1192,21 +1312,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 }
                 LAUNCH_CHECK();
                 {
-                    ProfScope prof(ctx, "diag_kernel", st);
-                    diag_kernel<<<diag_grid, 64, 0, st>>>(DS, nullptr, d_pairsN.as<Pair>(), d_nN0, d_nN, pair_cap,
-                                                          d_aa1.as<int32_t>(), d_aas.as<int32_t>(), P->band_width,
-                                                          P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+                    const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, b0, 0};
+                    int rc = evaluate(nullptr, d_pairsN.as<Pair>(), selN, d_best, kNewBit, 0);
+                    if (rc) return rc;
                 }
-                LAUNCH_CHECK();
-                {
-                    ProfScope prof(ctx, "align_kernel", st);
-                    align16_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsN.as<Pair>(), d_nN0, d_nN, pair_cap,
-                                                               d_aa1.as<int32_t>(), P->identity, b0, d_best, kNewBit);
-                    if (any_wide)
-                        align_kernel<<<align_grid, 256, 0, st>>>(DS, nullptr, d_pairsN.as<Pair>(), d_nN0, d_nN, pair_cap,
-                                                                 d_aa1.as<int32_t>(), P->identity, b0, d_best, kNewBit, 1);
-                }
-                LAUNCH_CHECK();
             }
             if (n_open == n_blk) break;  // that was the last block
         }
@@ -1290,10 +1399,15 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                                    hipMemcpyHostToDevice, st));
         }
         t_close += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
+        if (trace && std::getenv("PGX_TRACE")[0] == '2')
+            fprintf(stderr, "[pgx] sweep %4llu b0 %8u len %5u..%5u blocks %2llu reps +%5zu (total %7zu) pairsA %7u pairsN %7u  %.2f ms\n",
+                    (unsigned long long)S.sweeps, b0, h_len[b0], h_len[b0 + nb - 1],
+                    (unsigned long long)(n_blocks - blocks_before), rep_seq.size() - n_reps, rep_seq.size(), nA, nN,
+                    1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sweep0).count());
     }
     if (trace)
-        fprintf(stderr, "[pgx] sweeps %llu blocks %llu: loop %.1f ms = wait %.1f + block resolve %.1f + sweep close %.1f + "
-                "enqueue/other %.1f\n", (unsigned long long)S.sweeps, (unsigned long long)n_blocks,
+        fprintf(stderr, "[pgx] sweeps %llu blocks %llu (+%llu follow-up rounds): loop %.1f ms = wait %.1f + block resolve %.1f + sweep close %.1f + "
+                "enqueue/other %.1f\n", (unsigned long long)S.sweeps, (unsigned long long)n_blocks, (unsigned long long)n_rounds,
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count(), 1e3 * g_wait_s,
                 1e3 * t_resolve, 1e3 * t_close,
                 1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() - g_wait_s -
