@@ -24,6 +24,13 @@
  * member numbers, float identities, counters), and tests/test_cluster_oracle.py holds
  * known-answer cases (identical sequences, threshold straddling, discard length, ordering).
  *
+ * Nucleotide rules (alphabet = 1, the reference's `cd-hit-est -n 5 -c 0.8` call for files that
+ * end in .fna, pangenome.py:444) follow SURVEY.md A.1/A.2/A.4: A C G T/U -> 0..3, anything else
+ * 4 (N); words are base-4 k-mers, words containing N are skipped; the diagonal test counts
+ * shared 4-mers; scoring +2 / -2, gap open -6, extension -1; with both_strands the reverse
+ * complement of the query is tried when the forward strand finds no representative.
+ * Equally unpinned, for the same reason.
+ *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  */
 #include <stdint.h>
@@ -108,6 +115,12 @@ typedef struct {
     int64_t sub[23][23];
     pgx_cluster_stats st;
     int word_len;
+    int nt;            /* nucleotide rules */
+    int base;          /* word radix: 21 or 4 */
+    int kd;            /* k-mer length of the diagonal test: 2 or 4 */
+    int nkd;           /* number of diagonal-test k-mer codes: 441 or 256 */
+    int64_t gap_open, gap_ext;
+    uint8_t *rc_buf;   /* reverse complement of the current query */
 } state_t;
 
 static int cmp_i32(const void *a, const void *b) {
@@ -119,15 +132,18 @@ static int cmp_i32(const void *a, const void *b) {
  * runs to (code, multiplicity) with the multiplicity on the first element of the run. */
 static uint32_t encode_words(state_t *S, const uint8_t *seq, uint32_t len) {
     const int k = S->word_len;
-    const uint32_t nw = len - k + 1;
-    for (uint32_t j = 0; j < nw; ++j) {
+    const uint32_t npos = len - k + 1;
+    uint32_t nw = 0;
+    for (uint32_t j = 0; j < npos; ++j) {
         int32_t code = 0;
-        for (int t = 0; t < k; ++t) code = code * NAA1 + seq[j + t];
-        S->word_codes[j] = code;
+        int bad = 0;
+        for (int t = 0; t < k; ++t) { code = code * S->base + seq[j + t]; bad |= seq[j + t] >= S->base; }
+        if (S->nt && bad) continue; /* nucleotide words containing N are skipped */
+        S->word_codes[nw++] = code;
     }
     qsort(S->word_codes, nw, sizeof(int32_t), cmp_i32);
     for (uint32_t j = 0; j < nw; ++j) S->word_mult[j] = 1;
-    for (uint32_t j = nw - 1; j > 0; --j)
+    for (uint32_t j = nw; j-- > 1;)
         if (S->word_codes[j] == S->word_codes[j - 1]) {
             S->word_mult[j - 1] += S->word_mult[j];
             S->word_mult[j] = 0;
@@ -180,21 +196,34 @@ static int add_word_counts(state_t *S, uint32_t nw, uint32_t rep) {
     return 0;
 }
 
-/* "ComputeAAP": positions of every 2-mer of the query, bucketed by 2-mer code. */
+/* code of the diagonal-test k-mer starting at seq[j] (2-mer base 21, or 4-mer base 4), -1 when a
+ * nucleotide k-mer contains N; *cpx = 1 + number of adjacent unequal residues inside it */
+static int kd_code(const state_t *S, const uint8_t *seq, int j, int *cpx) {
+    int code = 0, c = 1;
+    for (int t = 0; t < S->kd; ++t) {
+        if (S->nt && seq[j + t] >= 4) return -1;
+        code = code * S->base + seq[j + t];
+        if (t) c += seq[j + t] != seq[j + t - 1];
+    }
+    if (cpx) *cpx = c;
+    return code;
+}
+
+/* "ComputeAAP": positions of every diagonal-test k-mer of the query, bucketed by code. */
 static void compute_aap(state_t *S, const uint8_t *seq, uint32_t len) {
-    const int n2 = NAA1 * NAA1;
+    const int n2 = S->nkd, last = (int)len - S->kd;
     memset(S->taap, 0, n2 * sizeof(int32_t));
-    for (uint32_t j = 0; j + 1 < len; ++j) S->taap[seq[j] * NAA1 + seq[j + 1]]++;
+    for (int j = 0; j <= last; ++j) { const int c = kd_code(S, seq, j, NULL); if (c >= 0) S->taap[c]++; }
     int32_t mm = 0;
     for (int c = 0; c < n2; ++c) { S->aap_begin[c] = mm; mm += S->taap[c]; S->taap[c] = 0; }
-    for (uint32_t j = 0; j + 1 < len; ++j) {
-        const int c = seq[j] * NAA1 + seq[j + 1];
-        S->aap_list[S->aap_begin[c] + S->taap[c]++] = (int32_t)j;
+    for (int j = 0; j <= last; ++j) {
+        const int c = kd_code(S, seq, j, NULL);
+        if (c >= 0) S->aap_list[S->aap_begin[c] + S->taap[c]++] = (int32_t)j;
     }
 }
 
-/* "diag_test_aapn" (A.4 step 4): histogram of shared 2-mers per diagonal, best window of
- * `band_width` diagonals, centre = best single diagonal, edges trimmed. */
+/* "diag_test_aapn" / "_est" (A.4 step 4): histogram of shared k-mers per diagonal, best window
+ * of `band_width` diagonals, centre = best single diagonal, edges trimmed. */
 static void diag_test(state_t *S, const uint8_t *seq2, int len1, int len2, int band_width,
                       int required_aa1, double cluster_thd, int *best_sum, int *band_left,
                       int *band_center, int *band_right) {
@@ -203,9 +232,10 @@ static void diag_test(state_t *S, const uint8_t *seq2, int len1, int len2, int b
     memset(ds, 0, (size_t)nall * sizeof(int32_t));
     memset(ds2, 0, (size_t)nall * sizeof(int32_t));
     int i1 = len1 - 1;
-    for (int i = 0; i < len2 - 1; ++i, ++i1) {
-        const int c22 = seq2[i] * NAA1 + seq2[i + 1];
-        const int cpx = 1 + (seq2[i] != seq2[i + 1]);
+    for (int i = 0; i <= len2 - S->kd; ++i, ++i1) {
+        int cpx;
+        const int c22 = kd_code(S, seq2, i, &cpx);
+        if (c22 < 0) continue;
         const int cnt = S->taap[c22];
         if (!cnt) continue;
         const int32_t *pos = S->aap_list + S->aap_begin[c22];
@@ -264,7 +294,7 @@ static int band_align(state_t *S, const uint8_t *seq1, const uint8_t *seq2, int 
     int64_t *sm = S->score_mat; uint8_t *bm = S->back_mat;
 #define SM(i, j1) sm[(size_t)(i) * bw1 + (j1)]
 #define BM(i, j1) bm[(size_t)(i) * bw1 + (j1)]
-    const int64_t gap = (int64_t)SCORE_SCALE * GAP_OPEN, ext = (int64_t)SCORE_SCALE * GAP_EXT;
+    const int64_t gap = S->gap_open, ext = S->gap_ext;
     if (band_left < 0) { /* left border: leading query residues hang over */
         const int tband = band_right < 0 ? band_right : 0;
         for (int k = band_left; k <= tband; ++k) {
@@ -327,15 +357,14 @@ static int band_align(state_t *S, const uint8_t *seq1, const uint8_t *seq2, int 
     return 0;
 }
 
-/* "CheckOneAA": returns 1 and fills rep/identity when the query joins a representative. */
-static int check_one(state_t *S, uint32_t q, const pgx_cluster_params *P, uint32_t *nw_out,
-                     uint32_t *hit_rep, float *hit_iden) {
-    const uint8_t *seq = S->seq[q];
-    const int len = (int)S->len[q];
+/* One strand of "CheckOneAA" / "CheckOneEST": `seq` is the query as given or its reverse
+ * complement. Returns 1 and fills rep/identity when it joins a representative. */
+static int check_strand(state_t *S, const uint8_t *seq, int len, const pgx_cluster_params *P,
+                        uint32_t *nw_out, uint32_t *hit_rep, float *hit_iden) {
     const int required_aa1 = (int)(P->identity * (double)len);
     int required_aas, required_aan;
     if (P->identity > 0.95) {
-        required_aas = len - 2 + 1 - (len - required_aa1) * 2;
+        required_aas = len - S->kd + 1 - (len - required_aa1) * S->kd;
         required_aan = len - S->word_len + 1 - (len - required_aa1) * S->word_len;
     } else {
         required_aas = (int)(P->aas_cutoff * (double)len);
@@ -373,14 +402,40 @@ static int check_one(state_t *S, uint32_t q, const pgx_cluster_params *P, uint32
     return 0;
 }
 
+/* forward strand first; for nucleotides with both_strands the reverse complement second */
+static int check_one(state_t *S, uint32_t q, const pgx_cluster_params *P, uint32_t *nw_out,
+                     uint32_t *hit_rep, float *hit_iden, int *hit_strand) {
+    const uint8_t *seq = S->seq[q];
+    const int len = (int)S->len[q];
+    *hit_strand = 0;
+    int hit = check_strand(S, seq, len, P, nw_out, hit_rep, hit_iden);
+    if (hit != 0 || !S->nt || !P->both_strands) return hit;
+    for (int i = 0; i < len; ++i) {
+        const uint8_t b = seq[len - 1 - i];
+        S->rc_buf[i] = b < 4 ? (uint8_t)(3 - b) : b;
+    }
+    uint32_t nw_rc;
+    hit = check_strand(S, S->rc_buf, len, P, &nw_rc, hit_rep, hit_iden);
+    if (hit == 1) { *hit_strand = 1; return 1; }
+    if (hit < 0) return hit;
+    *nw_out = encode_words(S, seq, (uint32_t)len); /* a new representative stores its forward words */
+    return 0;
+}
+
 int pgxo_cluster_greedy(const uint8_t *residues, const uint64_t *offsets, uint32_t n,
                         const pgx_cluster_params *P, int32_t *out_cluster, int32_t *out_member,
                         float *out_identity, uint8_t *out_strand, uint32_t *out_n_clusters,
                         pgx_cluster_stats *stats) {
-    if (!P || P->alphabet != 0) return PGX_ERR_INVALID; /* protein rules only (K1) */
-    if (P->word_len < 2 || P->word_len > MAX_NAA) return PGX_ERR_INVALID;
+    if (!P || (P->alphabet != 0 && P->alphabet != 1)) return PGX_ERR_INVALID;
+    if (P->word_len < 2 || P->word_len > (P->alphabet ? 11 : MAX_NAA)) return PGX_ERR_INVALID;
     state_t S; memset(&S, 0, sizeof(S));
     S.word_len = P->word_len;
+    S.nt = P->alphabet == 1;
+    S.base = S.nt ? 4 : NAA1;
+    S.kd = S.nt ? 4 : 2;
+    S.nkd = S.nt ? 256 : NAA1 * NAA1;
+    S.gap_open = (int64_t)SCORE_SCALE * (S.nt ? -6 : GAP_OPEN);
+    S.gap_ext = (int64_t)SCORE_SCALE * (S.nt ? -1 : GAP_EXT);
     S.st.n_input = n;
     int rc = PGX_ERR_NOMEM;
 
@@ -397,7 +452,9 @@ int pgxo_cluster_greedy(const uint8_t *residues, const uint64_t *offsets, uint32
             for (uint64_t p = offsets[i]; p < offsets[i + 1]; ++p) {
                 uint8_t ch = residues[p];
                 if (ch >= 'a' && ch <= 'z') ch -= 32;
-                if (ch >= 'A' && ch <= 'Z') enc[w++] = (uint8_t)AA2IDX[ch - 'A'];
+                if (ch >= 'A' && ch <= 'Z')
+                    enc[w++] = S.nt ? (uint8_t)(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : (ch == 'T' || ch == 'U') ? 3 : 4)
+                                    : (uint8_t)AA2IDX[ch - 'A'];
             }
             const uint64_t L = w - eoff[i];
             if (L > max_len) max_len = (uint32_t)L;
@@ -431,7 +488,7 @@ int pgxo_cluster_greedy(const uint8_t *residues, const uint64_t *offsets, uint32
             if ((int)S.len[k] < S.word_len) { rc = PGX_ERR_INVALID; goto done; } /* needs min_length >= word_len-1 */
         }
         S.n_codes = 1;
-        for (int t = 0; t < S.word_len; ++t) S.n_codes *= NAA1;
+        for (int t = 0; t < S.word_len; ++t) S.n_codes *= (uint32_t)S.base;
         S.table = (postlist_t *)calloc(S.n_codes, sizeof(postlist_t));
         S.rep_seq = (uint32_t *)malloc(((size_t)S.n ? S.n : 1) * sizeof(uint32_t));
         S.word_codes = (int32_t *)malloc(((size_t)max_len + 1) * sizeof(int32_t));
@@ -443,24 +500,28 @@ int pgxo_cluster_greedy(const uint8_t *residues, const uint64_t *offsets, uint32
         S.aap_list = (int32_t *)malloc(((size_t)max_len + 1) * sizeof(int32_t));
         S.diag_score = (int32_t *)malloc(((size_t)max_len * 2 + 2) * sizeof(int32_t));
         S.diag_score2 = (int32_t *)malloc(((size_t)max_len * 2 + 2) * sizeof(int32_t));
+        S.rc_buf = (uint8_t *)malloc((size_t)max_len + 1);
         if (!S.table || !S.rep_seq || !S.word_codes || !S.word_mult || !S.look || !S.index_map ||
-            !S.taap || !S.aap_begin || !S.aap_list || !S.diag_score || !S.diag_score2) goto done;
+            !S.taap || !S.aap_begin || !S.aap_list || !S.diag_score || !S.diag_score2 || !S.rc_buf) goto done;
     }
     {
         int k = 0;
         for (int i = 0; i < 23; ++i)
             for (int j = 0; j <= i; ++j)
                 S.sub[i][j] = S.sub[j][i] = (int64_t)SCORE_SCALE * BLOSUM62_TRI[k++];
+        if (S.nt) /* A.1: match +2, mismatch -2 over the indices 0..4 */
+            for (int i = 0; i < 23; ++i)
+                for (int j = 0; j < 23; ++j) S.sub[i][j] = (int64_t)SCORE_SCALE * (i == j ? 2 : -2);
     }
     uint32_t *member_count = (uint32_t *)calloc((size_t)S.n + 1, sizeof(uint32_t));
     if (!member_count) goto done;
 
     /* main greedy pass ("DoClustering" / "ClusterOne"), unchunked (A.6) */
     for (uint32_t q = 0; q < S.n; ++q) {
-        uint32_t nw = 0, hit_rep = 0; float hit_iden = 0.0f;
+        uint32_t nw = 0, hit_rep = 0; float hit_iden = 0.0f; int hit_strand = 0;
         S.st.n_clustered++;
         S.st.sum_len_queries += S.len[q];
-        const int hit = check_one(&S, q, P, &nw, &hit_rep, &hit_iden);
+        const int hit = check_one(&S, q, P, &nw, &hit_rep, &hit_iden, &hit_strand);
         if (hit < 0) { free(member_count); goto done; }
         uint32_t cluster;
         if (hit) {
@@ -475,6 +536,7 @@ int pgxo_cluster_greedy(const uint8_t *residues, const uint64_t *offsets, uint32
         if (out_cluster) out_cluster[o] = (int32_t)cluster;
         if (out_member) out_member[o] = (int32_t)member_count[cluster];
         if (out_identity) out_identity[o] = hit ? hit_iden : 0.0f;
+        if (out_strand) out_strand[o] = (uint8_t)(hit ? hit_strand : 0);
         member_count[cluster]++;
     }
     free(member_count);
@@ -486,7 +548,7 @@ done:
     if (S.table) { for (uint32_t c = 0; c < S.n_codes; ++c) free(S.table[c].items); }
     free(S.table); free(S.rep_seq); free(S.word_codes); free(S.word_mult); free(S.look);
     free(S.index_map); free(S.taap); free(S.aap_begin); free(S.aap_list); free(S.diag_score);
-    free(S.diag_score2); free(S.score_mat); free(S.back_mat); free((void *)S.seq); free(S.len);
+    free(S.diag_score2); free(S.rc_buf); free(S.score_mat); free(S.back_mat); free((void *)S.seq); free(S.len);
 done0:
     free(enc); free(eoff); free(order);
     return rc;

@@ -93,7 +93,20 @@ struct DevSeqs {
     const uint32_t *wcode;  // distinct word codes, ascending, at off[k]
     const uint16_t *wmult;  // multiplicities
     const uint32_t *wcnt;   // [n] number of distinct words
+    // Nucleotide clustering with both strands stores the reverse complement of sequence k as
+    // the virtual sequence n_fwd + k (same length, own residues and word list): comparing the
+    // reverse strand of a query is then an ordinary comparison of that virtual sequence.
+    uint32_t n_fwd;         // number of real sequences
+    int32_t base;           // word / k-mer radix: 21 (protein) or 4 (nucleotide)
+    int32_t kd;             // k-mer length of the diagonal test: 2 or 4
+    int32_t nt;             // nucleotide rules
 };
+__device__ __forceinline__ uint32_t real_of(const DevSeqs &S, uint32_t k) { return k >= S.n_fwd ? k - S.n_fwd : k; }
+// batch slot -> sequence: slots [0, nbq) are the sweep's queries b0.., slots [nbq, 2 nbq) their
+// reverse complements (present only for nucleotides with both strands)
+__device__ __forceinline__ uint32_t slot_seq(const DevSeqs &S, uint32_t b0, uint32_t nbq, uint32_t s) {
+    return s < nbq ? b0 + s : S.n_fwd + b0 + (s - nbq);
+}
 
 // ----------------------------------------------------------------------------------------
 // prep: letter count per input sequence, then gather + encode into sorted order
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(256) void encode_gather_kernel(const uint8_t *__res
                                                            const uint64_t *__restrict__ in_off,
                                                            const uint32_t *__restrict__ order,
                                                            const uint64_t *__restrict__ out_off,
-                                                           uint8_t *__restrict__ out, uint32_t n) {
+                                                           uint8_t *__restrict__ out, uint32_t n, int nt) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (k >= n) return;
@@ -138,8 +151,27 @@ __global__ __launch_bounds__(256) void encode_gather_kernel(const uint8_t *__res
         const uint8_t ch = p < e ? in[p] : 0;
         const bool ok = is_letter(ch);
         const unsigned long long m = __ballot(ok);
-        if (ok) out[w + __popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)kAa2Idx_dev[(ch & 0xDF) - 'A'];
+        if (ok) {
+            const uint8_t up = ch & 0xDF;
+            const uint8_t idx = nt ? (uint8_t)(up == 'A' ? 0 : up == 'C' ? 1 : up == 'G' ? 2 : (up == 'T' || up == 'U') ? 3 : 4)
+                                   : (uint8_t)kAa2Idx_dev[up - 'A'];
+            out[w + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+        }
         w += __popcll(m);
+    }
+}
+
+// reverse complement of sequence k written as virtual sequence n + k (one wave per sequence)
+__global__ __launch_bounds__(256) void revcomp_kernel(uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
+                                                     const uint32_t *__restrict__ len, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const uint64_t src = off[k], dst = off[n + k];
+    const uint32_t L = len[k];
+    for (uint32_t i = lane; i < L; i += 64) {
+        const uint8_t b = res[src + L - 1 - i];
+        res[dst + i] = b < 4 ? (uint8_t)(3 - b) : b;
     }
 }
 
@@ -150,7 +182,7 @@ template <int NCAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restrict__ res,
                                                         const uint64_t *__restrict__ off,
                                                         const uint32_t *__restrict__ len, uint32_t k0,
-                                                        uint32_t k1, int word_len,
+                                                        uint32_t k1, int word_len, int base, int nt,
                                                         uint32_t *__restrict__ wcode,
                                                         uint16_t *__restrict__ wmult,
                                                         uint32_t *__restrict__ wcnt) {
@@ -166,7 +198,9 @@ __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restric
         uint32_t key = kSentinel;
         if (i < nw) {
             key = 0;
-            for (int t = 0; t < word_len; ++t) key = key * kNAA1 + s[i + t];
+            bool bad = false;
+            for (int t = 0; t < word_len; ++t) { key = key * (uint32_t)base + s[i + t]; bad |= s[i + t] >= base; }
+            if (nt && bad) key = kSentinel;  // words containing N are skipped (they sort behind all real words)
         }
         keys[i] = key;
     }
@@ -188,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restric
     const uint32_t beg = tid * C;
     uint32_t heads = 0;
     for (uint32_t i = beg; i < beg + C; ++i)
-        heads += (i < nw) && (i == 0 || keys[i] != keys[i - 1]);
+        heads += (i < nw) && keys[i] != kSentinel && (i == 0 || keys[i] != keys[i - 1]);
     part[tid] = heads;
     __syncthreads();
     for (uint32_t d = 1; d < THREADS; d <<= 1) {  // inclusive Hillis-Steele scan
@@ -200,7 +234,7 @@ __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restric
     uint32_t idx = part[tid] - heads;
     if (tid == THREADS - 1) wcnt[k] = part[tid];
     for (uint32_t i = beg; i < beg + C; ++i) {
-        if ((i < nw) && (i == 0 || keys[i] != keys[i - 1])) {
+        if ((i < nw) && keys[i] != kSentinel && (i == 0 || keys[i] != keys[i - 1])) {
             uint32_t j = i + 1;
             while (j < nw && keys[j] == keys[i]) ++j;
             wcode[o + idx] = keys[i];
@@ -213,21 +247,21 @@ __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restric
 // ----------------------------------------------------------------------------------------
 // batch index: CSR by word code over the batch's distinct words
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void index_hist_kernel(DevSeqs S, uint32_t b0, uint32_t nb,
+__global__ __launch_bounds__(256) void index_hist_kernel(DevSeqs S, uint32_t b0, uint32_t nb, uint32_t nbq,
                                                         uint32_t *__restrict__ bi_cnt) {
-    const uint32_t k = b0 + blockIdx.x;
     if (blockIdx.x >= nb) return;
+    const uint32_t k = slot_seq(S, b0, nbq, blockIdx.x);
     const uint64_t o = S.off[k];
     const uint32_t n = S.wcnt[k];
     for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&bi_cnt[S.wcode[o + i]], 1u);
 }
 
-__global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t b0, uint32_t nb,
+__global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t b0, uint32_t nb, uint32_t nbq,
                                                            const uint32_t *__restrict__ bi_off,
                                                            uint32_t *__restrict__ bi_fill,
                                                            uint32_t *__restrict__ bi_ent) {
-    const uint32_t k = b0 + blockIdx.x;
     if (blockIdx.x >= nb) return;
+    const uint32_t k = slot_seq(S, b0, nbq, blockIdx.x);
     const uint64_t o = S.off[k];
     const uint32_t n = S.wcnt[k];
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
@@ -254,10 +288,13 @@ enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2 };
 constexpr unsigned long long kNoBest = ~0ull;
 constexpr uint32_t kNewBit = 0x80000000u;
 
-template <int MODE>
+// NT adds per-query visit counters for the reverse-strand slots: the one-by-one pass only walks
+// a query's reverse-complement words when its forward strand found no representative, so
+// those visits are attributed per query (rc_visits) and summed on the host for such queries.
+template <int MODE, bool NT>
 __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *__restrict__ table,
                                                    const uint32_t *__restrict__ d_ntable,
-                                                   uint32_t ntable_host, uint32_t b0, uint32_t nb,
+                                                   uint32_t ntable_host, uint32_t b0, uint32_t nb, uint32_t nbq,
                                                    const uint32_t *__restrict__ bi_off,
                                                    const uint32_t *__restrict__ bi_ent,
                                                    const int32_t *__restrict__ req_aan,
@@ -265,13 +302,15 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                                                    const uint8_t *__restrict__ qflag,
                                                    Pair *__restrict__ pairs, uint32_t *__restrict__ n_pairs,
                                                    uint32_t pair_cap,
-                                                   unsigned long long *__restrict__ visits) {
+                                                   unsigned long long *__restrict__ visits,
+                                                   unsigned long long *__restrict__ rc_visits) {
     __shared__ uint32_t cnt[kBatchCap];
     __shared__ uint32_t minc[kBatchCap];
+    __shared__ uint32_t vis[NT ? kBatchCap : 1];
     __shared__ unsigned long long wg_visits;
     const uint32_t ntable = d_ntable ? *d_ntable : ntable_host;
     for (uint32_t r = blockIdx.x; r < ntable; r += gridDim.x) {
-        for (uint32_t q = threadIdx.x; q < nb; q += 256) { cnt[q] = 0u; minc[q] = kSentinel; }
+        for (uint32_t q = threadIdx.x; q < nb; q += 256) { cnt[q] = 0u; minc[q] = kSentinel; if (NT) vis[q] = 0u; }
         if (threadIdx.x == 0) wg_visits = 0ull;
         __syncthreads();
         const uint32_t k = table[r];
@@ -285,27 +324,31 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
             for (uint32_t e = lo; e < hi; ++e) {
                 const uint32_t ent = bi_ent[e];
                 const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
-                if (MODE != MODE_TABLE && b0 + q <= k) continue;  // only queries after the representative
+                if (MODE != MODE_TABLE && b0 + (q >= nbq ? q - nbq : q) <= k) continue;  // only queries after the representative
                 atomicAdd(&cnt[q], m < mq ? m : mq);
                 atomicMin(&minc[q], code);
-                ++my_visits;
+                if (NT && q >= nbq) atomicAdd(&vis[q], 1u);  // reverse strand: attributed to the query
+                else ++my_visits;
             }
         }
         if (MODE != MODE_BLOCK && my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
         __syncthreads();
         for (uint32_t q = threadIdx.x; q < nb; q += 256) {
             const uint32_t c = cnt[q];
-            if (c == 0u || (int32_t)c < req_aan[b0 + q]) continue;
+            const uint32_t ql = q >= nbq ? q - nbq : q;  // the query's local index; q >= nbq = reverse strand
+            if (NT && MODE != MODE_BLOCK && q >= nbq && vis[q]) atomicAdd(&rc_visits[ql], (unsigned long long)vis[q]);
+            if (c == 0u || (int32_t)c < req_aan[b0 + ql]) continue;
             if (MODE == MODE_NEW) {
-                if (qflag[q]) continue;  // resolved inside a block already
-                const unsigned long long bo = best[q];
-                if (bo != kNoBest && minc[q] >= (uint32_t)(bo >> 32)) continue;
+                if (qflag[ql]) continue;  // resolved inside a block already
+                const unsigned long long bo = best[ql];
+                const unsigned long long hi = ((unsigned long long)(q >= nbq) << 63) | ((unsigned long long)minc[q] << 32);
+                if (bo != kNoBest && hi >= (bo & 0xFFFFFFFF00000000ull)) continue;
             }
-            if (MODE == MODE_BLOCK && !qflag[q]) continue;  // not in the current block
+            if (MODE == MODE_BLOCK && !qflag[ql]) continue;  // not in the current block
             const uint32_t slot = atomicAdd(n_pairs, 1u);
             if (slot < pair_cap) {
                 Pair p;
-                p.q = b0 + q; p.r = MODE == MODE_TABLE ? r : k; p.cnt = c; p.minc = minc[q];
+                p.q = slot_seq(S, b0, nbq, q); p.r = MODE == MODE_TABLE ? r : k; p.cnt = c; p.minc = minc[q];
                 p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
                 pairs[slot] = p;
             }
@@ -363,11 +406,12 @@ __global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restr
 // without one (and without a representative so far) is certainly a new representative
 __global__ __launch_bounds__(256) void mark_candidates_kernel(const Pair *__restrict__ pairs,
                                                              const uint32_t *__restrict__ d_n, uint32_t cap,
-                                                             uint32_t b0, uint8_t *__restrict__ has_cand) {
+                                                             uint32_t b0, uint32_t n_fwd,
+                                                             uint8_t *__restrict__ has_cand) {
     uint32_t n = *d_n;
     if (n > cap) n = cap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        has_cand[pairs[i].q - b0] = 1;
+        has_cand[(pairs[i].q >= n_fwd ? pairs[i].q - n_fwd : pairs[i].q) - b0] = 1;
 }
 
 // After the first in-block round: a member that has candidates but was accepted by none of
@@ -375,11 +419,12 @@ __global__ __launch_bounds__(256) void mark_candidates_kernel(const Pair *__rest
 // skip2[u] = 0 exactly for those, so the second round evaluates the pairs against them.
 __global__ __launch_bounds__(256) void mark_accepted_kernel(const Pair *__restrict__ pairs,
                                                            const uint32_t *__restrict__ d_n, uint32_t cap,
-                                                           uint32_t b0, uint8_t *__restrict__ accepted) {
+                                                           uint32_t b0, uint32_t n_fwd,
+                                                           uint8_t *__restrict__ accepted) {
     uint32_t n = *d_n;
     if (n > cap) n = cap;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        if (pairs[i].flags & F_ACCEPT) accepted[pairs[i].q - b0] = 1;
+        if (pairs[i].flags & F_ACCEPT) accepted[(pairs[i].q >= n_fwd ? pairs[i].q - n_fwd : pairs[i].q) - b0] = 1;
 }
 __global__ __launch_bounds__(256) void likely_rep_kernel(const uint8_t *__restrict__ has_cand,
                                                         const uint8_t *__restrict__ accepted, uint32_t nb,
@@ -453,6 +498,21 @@ __device__ void band_from_histogram(DiagPtr d, int len1, int len2, int band_widt
     *bl = from - len1 + 1; *br = end - len1 + 1; *bc = imax - len1 + 1; *best_sum = best_score;
 }
 
+// code of the diagonal-test k-mer at s[j] (2-mer base 21 or 4-mer base 4), -1 if a nucleotide
+// k-mer contains N; *cpx = 1 + number of adjacent unequal residues inside it
+__device__ __forceinline__ int kd_code(const DevSeqs &S, const uint8_t *__restrict__ s, int j, int *cpx) {
+    int code = 0, c = 1;
+    bool bad = false;
+    for (int t = 0; t < S.kd; ++t) {
+        const int r = s[j + t];
+        bad |= r >= S.base;
+        code = code * S.base + r;
+        if (t) c += r != s[j + t - 1];
+    }
+    *cpx = c;
+    return (S.nt && bad) ? -1 : code;
+}
+
 // rep_seq == nullptr: p.r is already a sequence index (phase B)
 __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
                                                  Pair *__restrict__ pairs, PairSel sel,
@@ -466,20 +526,21 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
     __shared__ uint16_t alist[kDiagLdsCap];
     const uint32_t lane = threadIdx.x;
     const uint32_t np = sel_count(sel);
-    constexpr int N2 = kNAA1 * kNAA1;
+    const int N2 = S.nt ? 256 : kNAA1 * kNAA1;
     for (uint32_t w = blockIdx.x; w < np; w += gridDim.x) {
         const uint32_t p = sel_pair(sel, w);
         const Pair pr = pairs[p];
         if (sel.skip_flag && sel.skip_flag[pr.r - sel.b0]) continue;  // block-uniform
         if (sel.skip_evaluated && (pr.flags & F_EVAL)) continue;
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
+        const uint32_t k1r = real_of(S, k1);  // thresholds are the query's, whichever strand
         const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
         const uint8_t *s1 = S.res + S.off[k1];
         const uint8_t *s2 = S.res + S.off[k2];
         const int nall = len1 + len2 - 1;
         // only diagonals with an overlap of at least required_aa1 residues are ever read back
         // (band_b .. band_e of the sequential rule), so only that window is histogrammed
-        const int d_lo = req_aa1[k1] - 1 >= 0 ? req_aa1[k1] - 1 : 0;
+        const int d_lo = req_aa1[k1r] - 1 >= 0 ? req_aa1[k1r] - 1 : 0;
         const int d_hi = nall - d_lo;
         const int n_d = d_hi >= d_lo ? d_hi - d_lo + 1 : 0;
         const bool big = (uint32_t)n_d > kDiagLdsCap || (uint32_t)len1 > kDiagLdsCap;
@@ -489,7 +550,12 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
         for (int i = lane; i < n_d; i += 64) dg[i] = 0u;
         for (int c = lane; c < N2; c += 64) taap[c] = 0u;
         __syncthreads();
-        for (int j = lane; j < len1 - 1; j += 64) atomicAdd(&taap[s1[j] * kNAA1 + s1[j + 1]], 1u);
+        const int last1 = len1 - S.kd, last2 = len2 - S.kd;
+        for (int j = lane; j <= last1; j += 64) {
+            int cpx;
+            const int c = kd_code(S, s1, j, &cpx);
+            if (c >= 0) atomicAdd(&taap[c], 1u);
+        }
         __syncthreads();
         {   // exclusive scan of the 441 bucket sizes, 7 per lane
             uint32_t loc[7], sum = 0;
@@ -498,15 +564,19 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
             for (int t = 0; t < 7; ++t) { const int c = lane * 7 + t; if (c < N2) { abeg[c] = base; taap[c] = 0u; } base += loc[t]; }
         }
         __syncthreads();
-        for (int j = lane; j < len1 - 1; j += 64) {
-            const int c = s1[j] * kNAA1 + s1[j + 1];
+        for (int j = lane; j <= last1; j += 64) {
+            int cpx;
+            const int c = kd_code(S, s1, j, &cpx);
+            if (c < 0) continue;
             const uint32_t pos = abeg[c] + atomicAdd(&taap[c], 1u);
             if (big) al_big[pos] = (uint32_t)j; else alist[pos] = (uint16_t)j;
         }
         __syncthreads();
-        for (int i = lane; i < len2 - 1; i += 64) {
-            const int c = s2[i] * kNAA1 + s2[i + 1];
-            const uint32_t inc = 1u | ((1u + (s2[i] != s2[i + 1])) << 16);
+        for (int i = lane; i <= last2; i += 64) {
+            int cpx;
+            const int c = kd_code(S, s2, i, &cpx);
+            if (c < 0) continue;
+            const uint32_t inc = 1u | ((uint32_t)cpx << 16);
             const uint32_t b = abeg[c], e = b + taap[c];
             for (uint32_t t = b; t < e; ++t) {
                 const int j = big ? (int)al_big[t] : (int)alist[t];
@@ -518,9 +588,9 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
         if (lane == 0) {
             int best_sum, bl, bc, br;
             const int bw = band_width < len1 + len2 - 2 ? band_width : len1 + len2 - 2;
-            band_from_histogram(dg - d_lo, len1, len2, bw, req_aa1[k1], cluster_thd, &best_sum, &bl, &bc, &br);
+            band_from_histogram(dg - d_lo, len1, len2, bw, req_aa1[k1r], cluster_thd, &best_sum, &bl, &bc, &br);
             uint32_t fl = F_EVAL;
-            if (best_sum >= req_aas[k1]) fl |= F_DIAG_PASS;
+            if (best_sum >= req_aas[k1r]) fl |= F_DIAG_PASS;
             if (!(br >= len2 || bl <= -len1 || bl > br)) fl |= F_BAND_OK;
             if (br - bl + 1 > kMaxBand) fl |= F_TOO_BIG;
             pairs[p].best_sum = best_sum; pairs[p].band_left = bl; pairs[p].band_center = bc;
@@ -548,7 +618,8 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t v, int src_lane) {
 // score = ext * distance and never count as gap continuations. Returns the number of
 // identical pairs on the best path into the end cell (wave-uniform).
 __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2, int len1,
-                               int len2, int bl, int bc, int br, const int8_t *__restrict__ sub /*LDS 21x21*/) {
+                               int len2, int bl, int bc, int br, const int8_t *__restrict__ sub /*LDS 21x21*/,
+                               int gap_open, int gap_ext) {
     const int lane = threadIdx.x & 63;
     const int bw = br - bl + 1;
     const int j1 = lane;
@@ -559,7 +630,7 @@ __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__
     const int maxd = bc - bl;
     const int dist = j1 > maxd ? j1 - maxd : maxd - j1;
     const int64_t bonus = 4 - (dist & 3);
-    const int64_t gap = kScoreScale * kGapOpen, ext = kScoreScale * kGapExt;
+    const int64_t gap = kScoreScale * gap_open, ext = kScoreScale * gap_ext;
     int64_t sc = 0;
     int bk = BK_NONE, id = 0;
     const int t_last = 2 * len1 + bw - 1;
@@ -641,7 +712,8 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
     __shared__ int32_t tab[4][kNAA1 * kNAA1];
     __shared__ uint32_t seqbuf[16][kA16Slot / 4];
     for (int c = threadIdx.x; c < 4 * kNAA1 * kNAA1; c += 256) {
-        const int s = kBlosum62_dev[c % (kNAA1 * kNAA1)];
+        const int cc = c % (kNAA1 * kNAA1);
+        const int s = S.nt ? (cc / kNAA1 == cc % kNAA1 ? 2 : -2) : (int)kBlosum62_dev[cc];
         tab[c / (kNAA1 * kNAA1)][c % (kNAA1 * kNAA1)] = s * (1 << kScaleShift) + (s > 0 ? c / (kNAA1 * kNAA1) + 1 : 0);
     }
     __syncthreads();
@@ -649,7 +721,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
     const int lane = threadIdx.x & 63, gl = lane & 15;
     const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(seqbuf[slot]);
-    const int gap = kGapOpen * (1 << kScaleShift), ext = kGapExt * (1 << kScaleShift);
+    const int gap = (S.nt ? -6 : kGapOpen) * (1 << kScaleShift), ext = (S.nt ? -1 : kGapExt) * (1 << kScaleShift);
     constexpr int kNever = INT32_MIN / 2;
 
     for (uint32_t base = blockIdx.x * 16u; base < n; base += gridDim.x * 16u) {
@@ -768,14 +840,16 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
         const int e0 = __shfl(m0, src), e1 = __shfl(m1, src);
         const int iden = ((ce & 1) ? e1 : e0) >> 2;
         if (fast && gl == 0) {
-            bool ok = iden >= req_aa1[k1];
+            const uint32_t k1r = real_of(S, k1);
+            bool ok = iden >= req_aa1[k1r];
             if (ok) {
                 const float pc = (float)iden / (float)len1;
                 ok = !((double)pc < cluster_thd);
             }
             pairs[p].iden = iden;
             pairs[p].flags = pr.flags | F_ALIGNED | (ok ? F_ACCEPT : 0u);
-            if (ok && best) atomicMin(&best[k1 - b0], ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
+            if (ok && best)
+                atomicMin(&best[k1r - b0], ((unsigned long long)(k1 != k1r) << 63) | ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
         }
     }
 }
@@ -789,8 +863,10 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
                                                    uint32_t b0, unsigned long long *__restrict__ best,
                                                    uint32_t key_flag, int wide_only) {
     __shared__ int8_t sub[kNAA1 * kNAA1];
-    for (int c = threadIdx.x; c < kNAA1 * kNAA1; c += 256) sub[c] = kBlosum62_dev[c];
+    for (int c = threadIdx.x; c < kNAA1 * kNAA1; c += 256)
+        sub[c] = S.nt ? (int8_t)(c / kNAA1 == c % kNAA1 ? 2 : -2) : kBlosum62_dev[c];
     __syncthreads();
+    const int gap_open = S.nt ? -6 : kGapOpen, gap_ext = S.nt ? -1 : kGapExt;
     const uint32_t n = sel_count(sel);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t w = blockIdx.x * 4 + wave; w < n; w += gridDim.x * 4) {
@@ -801,8 +877,9 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
         const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
         if (wide_only && !pair_is_wide(len1, len2, pr.band_left, pr.band_right)) continue;
         const int iden = band_align_wave(S.res + S.off[k1], S.res + S.off[k2], len1, len2, pr.band_left,
-                                         pr.band_center, pr.band_right, sub);
-        bool ok = iden >= req_aa1[k1];
+                                         pr.band_center, pr.band_right, sub, gap_open, gap_ext);
+        const uint32_t k1r = real_of(S, k1);
+        bool ok = iden >= req_aa1[k1r];
         if (ok) {
             const float pc = (float)iden / (float)len1;
             ok = !((double)pc < cluster_thd);
@@ -810,7 +887,8 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
         if (lane == 0) {
             pairs[p].iden = iden;
             pairs[p].flags = pr.flags | F_ALIGNED | (ok ? F_ACCEPT : 0u);
-            if (ok && best) atomicMin(&best[k1 - b0], ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
+            if (ok && best)
+                atomicMin(&best[k1r - b0], ((unsigned long long)(k1 != k1r) << 63) | ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
         }
     }
 }
@@ -854,10 +932,12 @@ static inline hipError_t spin_sync(hipStream_t st) {
 
 template <int NCAP, int THREADS>
 int launch_words(pgx_ctx *ctx, hipStream_t st, const uint8_t *res, const uint64_t *off, const uint32_t *len,
-                 uint32_t k0, uint32_t k1, int word_len, uint32_t *wcode, uint16_t *wmult, uint32_t *wcnt) {
+                 uint32_t k0, uint32_t k1, int word_len, int base, int nt, uint32_t *wcode, uint16_t *wmult,
+                 uint32_t *wcnt) {
     if (k1 <= k0) return PGX_OK;
     ProfScope prof(ctx, "words_kernel", st);
-    words_kernel<NCAP, THREADS><<<k1 - k0, THREADS, 0, st>>>(res, off, len, k0, k1, word_len, wcode, wmult, wcnt);
+    words_kernel<NCAP, THREADS><<<k1 - k0, THREADS, 0, st>>>(res, off, len, k0, k1, word_len, base, nt, wcode, wmult,
+                                                             wcnt);
     LAUNCH_CHECK();
     return PGX_OK;
 }
@@ -872,8 +952,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_REQUIRE(ctx && P, "NULL argument");
     PGX_REQUIRE(n_in == 0 || (d_residues && d_offsets), "NULL sequence arrays");
     PGX_REQUIRE(out_cluster && out_member && out_identity, "NULL output arrays");
-    PGX_REQUIRE(P->alphabet == 0, "only protein rules (cd-hit) are implemented; nucleotide (cd-hit-est) is not");
-    PGX_REQUIRE(P->word_len >= 2 && P->word_len <= kMaxWordLen, "word_len must be 2..5");
+    PGX_REQUIRE(P->alphabet == 0 || P->alphabet == 1, "alphabet must be 0 (protein) or 1 (nucleotide)");
+    const bool nt = P->alphabet == 1;
+    const bool both = nt && P->both_strands != 0;
+    PGX_REQUIRE(P->word_len >= 2 && P->word_len <= (nt ? 11 : kMaxWordLen), "word_len must be 2..5 (protein) or 2..11 (nucleotide)");
     PGX_REQUIRE(P->identity >= 0.4 && P->identity <= 1.0, "identity must be 0.4..1.0");
     PGX_REQUIRE(P->band_width >= 1 && P->band_width <= kMaxBand, "band_width must be 1..64");
     PGX_REQUIRE(P->min_length >= P->word_len - 1, "min_length must be at least word_len - 1");
@@ -904,8 +986,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(hipStreamSynchronize(st));
     uint32_t max_len = 0;
     for (uint32_t i = 0; i < n_in; ++i) max_len = std::max(max_len, in_len[i]);
-    if (max_len > kMaxLen) {
-        pgx_set_error("pgx_cluster_greedy: sequence of %u residues exceeds the supported maximum %u", max_len, kMaxLen);
+    if (max_len > (nt ? kMaxLen / 2 : kMaxLen)) {  // (the 4-mer complexity weights need 18 bits beyond 16383)
+        pgx_set_error("pgx_cluster_greedy: sequence of %u residues exceeds the supported maximum %u", max_len,
+                      nt ? kMaxLen / 2 : kMaxLen);
         return PGX_ERR_CAPACITY;
     }
     std::vector<uint32_t> bucket((size_t)max_len + 2, 0);
@@ -918,11 +1001,13 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         if ((int)in_len[i] > P->min_length) order[bucket[max_len - in_len[i]]++] = i;
     if (n == 0) { if (stats) *stats = S; return PGX_OK; }
 
-    std::vector<uint64_t> h_off((size_t)n + 1);
-    std::vector<uint32_t> h_len(n);
+    // sequences n .. 2n-1 are the reverse complements (nucleotides, both strands)
+    const uint32_t nv = both ? 2 * n : n;
+    std::vector<uint64_t> h_off((size_t)nv + 1);
+    std::vector<uint32_t> h_len(nv);
     h_off[0] = 0;
-    for (uint32_t k = 0; k < n; ++k) { h_len[k] = in_len[order[k]]; h_off[k + 1] = h_off[k] + h_len[k]; }
-    const uint64_t total = h_off[n];
+    for (uint32_t k = 0; k < nv; ++k) { h_len[k] = in_len[order[k < n ? k : k - n]]; h_off[k + 1] = h_off[k] + h_len[k]; }
+    const uint64_t total = h_off[nv];
     // per-query thresholds in double, exactly as the sequential rule computes them
     std::vector<int32_t> h_aa1(n), h_aas(n), h_aan(n);
     for (uint32_t k = 0; k < n; ++k) {
@@ -930,7 +1015,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         const int aa1 = (int)(P->identity * (double)len);
         h_aa1[k] = aa1;
         if (P->identity > 0.95) {
-            h_aas[k] = len - 2 + 1 - (len - aa1) * 2;
+            h_aas[k] = len - (nt ? 4 : 2) + 1 - (len - aa1) * (nt ? 4 : 2);
             h_aan[k] = len - P->word_len + 1 - (len - aa1) * P->word_len;
         } else {
             h_aas[k] = (int)(P->aas_cutoff * (double)len);
@@ -943,13 +1028,14 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
 
     // ---- device buffers ------------------------------------------------------------------
     uint32_t n_codes = 1;
-    for (int t = 0; t < P->word_len; ++t) n_codes *= kNAA1;
-    const uint32_t pair_cap = 4u << 20;
-    const uint32_t pair_cap_k = kBlockCap * kBlockCap / 2 + 16;  // every pair of one block
+    for (int t = 0; t < P->word_len; ++t) n_codes *= nt ? 4u : (uint32_t)kNAA1;
+    const uint32_t sweep_cap = both ? kBatchCap / 2 : kBatchCap;  // queries per sweep (each strand takes a slot)
+    uint32_t pair_cap = 4u << 20;  // grows per sweep for nucleotides, whose word filter passes almost every pair
+    const uint32_t pair_cap_k = kBlockCap * kBlockCap + 16;  // every pair of one block, both strands
     uint64_t max_batch_words = 0;
-    for (uint32_t b0 = 0; b0 < n; b0 += kBatchCap) {
-        const uint32_t b1 = std::min(n, b0 + kBatchCap);
-        max_batch_words = std::max<uint64_t>(max_batch_words, h_off[b1] - h_off[b0]);
+    for (uint32_t b0 = 0; b0 < n; b0 += sweep_cap) {
+        const uint32_t b1 = std::min(n, b0 + sweep_cap);
+        max_batch_words = std::max<uint64_t>(max_batch_words, (h_off[b1] - h_off[b0]) * (both ? 2 : 1));
     }
     const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsCap;
     const uint32_t diag_grid = 2048, align_grid = 1024;
@@ -966,11 +1052,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
     PGX_HIP(d_res.alloc(total + 16));
-    PGX_HIP(d_off.alloc(((size_t)n + 1) * 8));
-    PGX_HIP(d_len.alloc((size_t)n * 4));
+    PGX_HIP(d_off.alloc(((size_t)nv + 1) * 8));
+    PGX_HIP(d_len.alloc((size_t)nv * 4));
     PGX_HIP(d_wcode.alloc((total + 16) * 4));
     PGX_HIP(d_wmult.alloc((total + 16) * 2));
-    PGX_HIP(d_wcnt.alloc((size_t)n * 4));
+    PGX_HIP(d_wcnt.alloc((size_t)nv * 4));
     PGX_HIP(d_aa1.alloc((size_t)n * 4));
     PGX_HIP(d_aas.alloc((size_t)n * 4));
     PGX_HIP(d_aan.alloc((size_t)n * 4));
@@ -979,7 +1065,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_bi_off.alloc(((size_t)n_codes + 1) * 4));
     PGX_HIP(d_bi_fill.alloc((size_t)n_codes * 4));
     PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
-    PGX_HIP(d_best_old.alloc(kBatchCap * 8));
+    PGX_HIP(d_best_old.alloc(kBatchCap * 16));  // best keys + reverse-strand visit counters
     PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
     PGX_HIP(d_new_list.alloc(kBatchCap * 4));
     PGX_HIP(d_flags.alloc(5 * kBatchCap));
@@ -998,12 +1084,15 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
 
     PGX_HIP(d_order.alloc((size_t)n * 4));
     PGX_HIP(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    PGX_HIP(hipMemcpyAsync(d_off.p, h_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, st));
-    PGX_HIP(hipMemcpyAsync(d_len.p, h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    PGX_HIP(hipMemcpyAsync(d_off.p, h_off.data(), ((size_t)nv + 1) * 8, hipMemcpyHostToDevice, st));
+    PGX_HIP(hipMemcpyAsync(d_len.p, h_len.data(), (size_t)nv * 4, hipMemcpyHostToDevice, st));
     {
         ProfScope prof(ctx, "encode_gather_kernel", st);
         encode_gather_kernel<<<(n + 3) / 4, 256, 0, st>>>(d_residues, d_offsets, d_order.as<uint32_t>(),
-                                                          d_off.as<uint64_t>(), d_res.as<uint8_t>(), n);
+                                                          d_off.as<uint64_t>(), d_res.as<uint8_t>(), n, nt ? 1 : 0);
+        if (both)
+            revcomp_kernel<<<(n + 3) / 4, 256, 0, st>>>(d_res.as<uint8_t>(), d_off.as<uint64_t>(),
+                                                        d_len.as<uint32_t>(), n);
     }
     LAUNCH_CHECK();
     PGX_HIP(hipMemcpyAsync(d_aa1.p, h_aa1.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1015,7 +1104,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     {
         const int wl = P->word_len;
         auto first_with_words_le = [&](uint32_t cap) {  // first k whose word count fits `cap`
-            return (uint32_t)(std::partition_point(h_len.begin(), h_len.end(),
+            return (uint32_t)(std::partition_point(h_len.begin(), h_len.begin() + n,
                                                    [&](uint32_t L) { return L - wl + 1 > cap; }) - h_len.begin());
         };
         const uint32_t k32 = first_with_words_le(32768), k8 = first_with_words_le(8192),
@@ -1024,13 +1113,18 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         int rc;
         uint8_t *r8 = d_res.as<uint8_t>(); uint64_t *o64 = d_off.as<uint64_t>(); uint32_t *l32 = d_len.as<uint32_t>();
         uint32_t *wc = d_wcode.as<uint32_t>(); uint16_t *wm = d_wmult.as<uint16_t>(); uint32_t *wn = d_wcnt.as<uint32_t>();
-        if ((rc = launch_words<32768, 1024>(ctx, st, r8, o64, l32, 0, k8, wl, wc, wm, wn))) return rc;
-        if ((rc = launch_words<8192, 1024>(ctx, st, r8, o64, l32, k8, k2, wl, wc, wm, wn))) return rc;
-        if ((rc = launch_words<2048, 256>(ctx, st, r8, o64, l32, k2, k5, wl, wc, wm, wn))) return rc;
-        if ((rc = launch_words<512, 128>(ctx, st, r8, o64, l32, k5, n, wl, wc, wm, wn))) return rc;
+        const int base = nt ? 4 : kNAA1;
+        for (uint32_t half = 0; half < (both ? 2u : 1u); ++half) {  // the reverse complements have the same lengths
+            const uint32_t o = half * n;
+            if ((rc = launch_words<32768, 1024>(ctx, st, r8, o64, l32, o, o + k8, wl, base, nt, wc, wm, wn))) return rc;
+            if ((rc = launch_words<8192, 1024>(ctx, st, r8, o64, l32, o + k8, o + k2, wl, base, nt, wc, wm, wn))) return rc;
+            if ((rc = launch_words<2048, 256>(ctx, st, r8, o64, l32, o + k2, o + k5, wl, base, nt, wc, wm, wn))) return rc;
+            if ((rc = launch_words<512, 128>(ctx, st, r8, o64, l32, o + k5, o + n, wl, base, nt, wc, wm, wn))) return rc;
+        }
     }
     DevSeqs DS{d_res.as<uint8_t>(), d_off.as<uint64_t>(), d_len.as<uint32_t>(),
-               d_wcode.as<uint32_t>(), d_wmult.as<uint16_t>(), d_wcnt.as<uint32_t>()};
+               d_wcode.as<uint32_t>(), d_wmult.as<uint16_t>(), d_wcnt.as<uint32_t>(),
+               n, nt ? 4 : kNAA1, nt ? 4 : 2, nt ? 1 : 0};
     std::vector<uint32_t> h_wcnt(n);
     PGX_HIP(hipMemcpyAsync(h_wcnt.data(), d_wcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 
@@ -1049,11 +1143,20 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     // device counters: [0] pairsA, [1] pairsN, [2] pairsK, [3] pairsN range start, [4] block size, [5] open members
     uint32_t *d_nA = d_counters.as<uint32_t>(), *d_nN = d_nA + 1, *d_nK = d_nA + 2, *d_nN0 = d_nA + 3,
              *d_blk = d_nA + 4;
-    unsigned long long *d_best = d_best_old.as<unsigned long long>();
+    unsigned long long *d_best = d_best_old.as<unsigned long long>(), *d_rcvis = d_best + kBatchCap;
+    Pinned<unsigned long long> h_rcvis;
+    PGX_HIP(h_rcvis.reserve(kBatchCap));
+    uint64_t visits_rc = 0;
     uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + kBatchCap;
     std::vector<uint8_t> status(kBatchCap), won_new(kBatchCap);
-    std::vector<uint32_t> member_of(kBatchCap), winner_minc(kBatchCap), new_reps, order_k, rank_of(kBatchCap),
+    std::vector<uint8_t> strand_of(n, 0);
+    std::vector<unsigned long long> winner_key(kBatchCap);  // strand<<63 | minc<<32 | new<<31 | index of the winner
+    std::vector<uint32_t> member_of(kBatchCap), new_reps, order_k, rank_of(kBatchCap),
         bucket_k(kBlockCap + 2), fill_k(kBlockCap + 2), flight;
+    auto real = [&](uint32_t k) { return k >= n ? k - n : k; };
+    auto pair_key = [&](const Pair &pp, bool is_new) {
+        return ((unsigned long long)(pp.q >= n) << 63) | ((unsigned long long)pp.minc << 32) | (is_new ? kNewBit : 0u) | pp.r;
+    };
     Pinned<uint32_t> h_list;
     Pinned<Pair> h_gather;
     PGX_HIP(h_list.reserve(pair_cap_k)); PGX_HIP(h_gather.reserve(pair_cap_k));
@@ -1075,9 +1178,24 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     double t_resolve = 0.0, t_close = 0.0;
     uint64_t n_blocks = 0;
     g_wait_s = 0.0;
-    for (uint32_t b0 = 0; b0 < n; b0 += kBatchCap) {
-        const uint32_t nb = std::min(kBatchCap, n - b0);
+    for (uint32_t b0 = 0; b0 < n; b0 += sweep_cap) {
+        const uint32_t nb = std::min(sweep_cap, n - b0);  // queries of this sweep
+        const uint32_t ns = both ? 2 * nb : nb;           // batch slots: + one per reverse complement
         const uint32_t n_reps = (uint32_t)rep_seq.size();
+        if (nt) {  // at cd-hit-est's -n 5 -c 0.8 one shared word is enough: size the pair buffers for all pairs
+            const uint64_t need = (uint64_t)ns * ((uint64_t)n_reps + nb) + 1024;
+            if (need > (400ull << 20)) {
+                pgx_set_error("pgx_cluster_greedy: %llu candidate pairs in one sweep exceed the supported maximum",
+                              (unsigned long long)need);
+                return PGX_ERR_CAPACITY;
+            }
+            if (need > pair_cap) {
+                PGX_HIP(spin_sync(st));
+                pair_cap = (uint32_t)(need + need / 2);
+                PGX_HIP(d_pairsA.alloc((size_t)pair_cap * sizeof(Pair)));
+                PGX_HIP(d_pairsN.alloc((size_t)pair_cap * sizeof(Pair)));
+            }
+        }
         S.sweeps++;
         const auto t_sweep0 = std::chrono::steady_clock::now();
         const uint64_t blocks_before = n_blocks;
@@ -1089,10 +1207,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         PGX_HIP(hipMemsetAsync(d_bi_fill.p, 0, (size_t)n_codes * 4, st));
         PGX_HIP(hipMemsetAsync(d_counters.p, 0, 32, st));
         PGX_HIP(hipMemsetAsync(d_best, 0xFF, kBatchCap * 8, st));
+        if (both) PGX_HIP(hipMemsetAsync(d_rcvis, 0, kBatchCap * 8, st));
         PGX_HIP(hipMemsetAsync(d_done, 0, 2 * kBatchCap, st));
         {
             ProfScope prof(ctx, "index_hist_kernel", st);
-            index_hist_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_cnt.as<uint32_t>());
+            index_hist_kernel<<<ns, 256, 0, st>>>(DS, b0, ns, nb, d_bi_cnt.as<uint32_t>());
         }
         LAUNCH_CHECK();
         {
@@ -1102,7 +1221,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         }
         {
             ProfScope prof(ctx, "index_scatter_kernel", st);
-            index_scatter_kernel<<<nb, 256, 0, st>>>(DS, b0, nb, d_bi_off.as<uint32_t>(),
+            index_scatter_kernel<<<ns, 256, 0, st>>>(DS, b0, ns, nb, d_bi_off.as<uint32_t>(),
                                                      d_bi_fill.as<uint32_t>(), d_bi_ent.as<uint32_t>());
         }
         LAUNCH_CHECK();
@@ -1132,10 +1251,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         if (n_reps) {
             {
                 ProfScope prof(ctx, "count_kernel<table>", st);
-                count_kernel<MODE_TABLE><<<std::min(n_reps, 4096u), 256, 0, st>>>(
-                    DS, d_rep_seq.as<uint32_t>(), nullptr, n_reps, b0, nb, d_bi_off.as<uint32_t>(),
+                auto kern = nt ? count_kernel<MODE_TABLE, true> : count_kernel<MODE_TABLE, false>;
+                kern<<<std::min(n_reps, 4096u), 256, 0, st>>>(
+                    DS, d_rep_seq.as<uint32_t>(), nullptr, n_reps, b0, ns, nb, d_bi_off.as<uint32_t>(),
                     d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, nullptr, d_pairsA.as<Pair>(), d_nA,
-                    pair_cap, d_visits.as<unsigned long long>());
+                    pair_cap, d_visits.as<unsigned long long>(), d_rcvis);
             }
             LAUNCH_CHECK();
             {
@@ -1157,16 +1277,17 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             PGX_HIP(hipMemsetAsync(d_nK, 0, 4, st));
             {
                 ProfScope prof(ctx, "count_kernel<block>", st);
-                count_kernel<MODE_BLOCK><<<kBlockCap, 256, 0, st>>>(
-                    DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
-                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr);
+                auto kern = nt ? count_kernel<MODE_BLOCK, true> : count_kernel<MODE_BLOCK, false>;
+                kern<<<kBlockCap, 256, 0, st>>>(
+                    DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
+                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis);
             }
             LAUNCH_CHECK();
             // A block member without an earlier in-block candidate is certainly a new
             // representative; only pairs against those are evaluated up front. Whatever the
             // in-order walk on the host still needs afterwards goes through follow-up rounds.
             PGX_HIP(hipMemsetAsync(d_hascand, 0, 2 * kBatchCap, st));  // has_cand + accepted
-            mark_candidates_kernel<<<256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_nK, pair_cap_k, b0, d_hascand);
+            mark_candidates_kernel<<<256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_nK, pair_cap_k, b0, n, d_hascand);
             LAUNCH_CHECK();
             {
                 const PairSel selK{nullptr, d_nK, pair_cap_k, nullptr, 0, d_hascand, b0, 0};
@@ -1174,7 +1295,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 if (rc) return rc;
             }
             // second round on the device: pairs against likely (outlier) representatives
-            mark_accepted_kernel<<<256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_nK, pair_cap_k, b0, d_accepted);
+            mark_accepted_kernel<<<256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_nK, pair_cap_k, b0, n, d_accepted);
             likely_rep_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_hascand, d_accepted, nb, d_skip2);
             LAUNCH_CHECK();
             {
@@ -1205,11 +1326,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             // bucket the in-block pairs by query (counting sort on the query's rank in the block)
             for (uint32_t t = 0; t < n_blk; ++t) { rank_of[h_blk.p[t] - b0] = t; bucket_k[t] = 0; }
             bucket_k[n_blk] = 0;
-            for (uint32_t i = 0; i < nK; ++i) bucket_k[rank_of[hK.p[i].q - b0] + 1]++;
+            for (uint32_t i = 0; i < nK; ++i) bucket_k[rank_of[real(hK.p[i].q) - b0] + 1]++;
             for (uint32_t t = 0; t < n_blk; ++t) bucket_k[t + 1] += bucket_k[t];   // bucket t = [bucket_k[t], bucket_k[t+1])
             for (uint32_t t = 0; t < n_blk; ++t) fill_k[t] = bucket_k[t];
             order_k.resize(nK);
-            for (uint32_t i = 0; i < nK; ++i) order_k[fill_k[rank_of[hK.p[i].q - b0]]++] = i;
+            for (uint32_t i = 0; i < nK; ++i) order_k[fill_k[rank_of[real(hK.p[i].q) - b0]]++] = i;
             // In-order walk. For member q the sequential rule takes the accepted representative
             // with the smallest (minc, index) among its in-block candidates that ARE
             // representatives. Pairs that neither device round evaluated and that could precede
@@ -1235,7 +1356,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                             return PGX_ERR_CAPACITY;
                         }
                         if (!(pr.flags & F_ACCEPT)) continue;
-                        const unsigned long long key = ((unsigned long long)pr.minc << 32) | pr.r;
+                        const unsigned long long key = pair_key(pr, true);
                         if (su == ST_REP) { if (key < win) { win = key; win_iden = pr.iden; } }
                         else if (key < open_acc) open_acc = key;  // wins if that member turns out a representative
                     }
@@ -1243,12 +1364,12 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                     for (uint32_t e = lo; e < hi; ++e) {
                         const Pair &pr = hK.p[order_k[e]];
                         if (status[pr.r - b0] == ST_MEMBER || (pr.flags & F_EVAL)) continue;
-                        if ((((unsigned long long)pr.minc << 32) | pr.r) < win) { flight.push_back(order_k[e]); needs = true; }
+                        if (pair_key(pr, true) < win) { flight.push_back(order_k[e]); needs = true; }
                     }
                     if (needs || open_acc < win) { any_open = true; continue; }
                     if (win != kNoBest) {
-                        status[q] = ST_MEMBER; member_of[q] = (uint32_t)win; won_new[q] = 1;
-                        winner_minc[q] = (uint32_t)(win >> 32); iden_of[k] = win_iden;
+                        status[q] = ST_MEMBER; member_of[q] = (uint32_t)win & ~kNewBit; won_new[q] = 1;
+                        winner_key[q] = win; iden_of[k] = win_iden; strand_of[k] = (uint8_t)(win >> 63);
                     } else {
                         status[q] = ST_REP;
                     }
@@ -1278,12 +1399,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             for (uint32_t t = 0; t < n_blk; ++t) {
                 const uint32_t k = h_blk.p[t], q = k - b0;
                 if (status[q] == ST_REP) new_reps.push_back(k);
-                const unsigned long long win = status[q] == ST_MEMBER
-                    ? (((unsigned long long)winner_minc[q] << 32) | member_of[q]) : kNoBest;
+                const unsigned long long win = status[q] == ST_MEMBER ? winner_key[q] : kNoBest;
                 for (uint32_t e = bucket_k[t]; e < bucket_k[t + 1]; ++e) {
                     const Pair &pr = hK.p[order_k[e]];
                     if (status[pr.r - b0] != ST_REP) continue;
-                    if ((((unsigned long long)pr.minc << 32) | pr.r) > win) continue;
+                    if (pair_key(pr, true) > win) continue;
                     S.filter_pairs++;
                     if ((pr.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
                         S.aligned_pairs++;
@@ -1305,10 +1425,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb);
                 {
                     ProfScope prof(ctx, "count_kernel<new>", st);
-                    count_kernel<MODE_NEW><<<nr, 256, 0, st>>>(
-                        DS, d_new, nullptr, nr, b0, nb, d_bi_off.as<uint32_t>(),
+                    auto kern = nt ? count_kernel<MODE_NEW, true> : count_kernel<MODE_NEW, false>;
+                    kern<<<nr, 256, 0, st>>>(
+                        DS, d_new, nullptr, nr, b0, ns, nb, d_bi_off.as<uint32_t>(),
                         d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done, d_pairsN.as<Pair>(), d_nN,
-                        pair_cap, d_visits.as<unsigned long long>());
+                        pair_cap, d_visits.as<unsigned long long>(), d_rcvis);
                 }
                 LAUNCH_CHECK();
                 {
@@ -1322,6 +1443,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // ---- close the sweep ---------------------------------------------------------------
         PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
         PGX_HIP(hipMemcpyAsync(h_best.p, d_best, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
+        if (both) PGX_HIP(hipMemcpyAsync(h_rcvis.p, d_rcvis, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
         PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
         PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
         PGX_HIP(spin_sync(st));
@@ -1344,10 +1466,14 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             const unsigned long long key = h_best.p[q];
             if (key == kNoBest) { pgx_set_error("pgx_cluster_greedy: unresolved member after the last block"); return PGX_ERR_INTERNAL; }
             status[q] = ST_MEMBER;
-            winner_minc[q] = (uint32_t)(key >> 32);
+            winner_key[q] = key;
             won_new[q] = ((uint32_t)key & kNewBit) != 0;
             member_of[q] = (uint32_t)key & ~kNewBit;
+            strand_of[b0 + q] = (uint8_t)(key >> 63);
         }
+        if (both)  // reverse-strand word walks happen only for queries the forward strand did not place
+            for (uint32_t q = 0; q < nb; ++q)
+                if (status[q] == ST_REP || (winner_key[q] >> 63)) visits_rc += h_rcvis.p[q];
         // new representatives are numbered in sequence order
         for (uint32_t q = 0; q < nb; ++q)
             if (status[q] == ST_REP) {
@@ -1361,24 +1487,18 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 cluster_of[b0 + q] = won_new[q] ? cluster_of[member_of[q]] : (int32_t)member_of[q];
         // identities of the winners + the candidates the one-by-one pass would have examined
         auto examine = [&](const Pair &p, bool is_new, uint32_t len2) {
-            const uint32_t q = p.q - b0;
+            const uint32_t k = real(p.q), q = k - b0;
             if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) return false;
-            bool seen = status[q] == ST_REP;
-            if (!seen) {
-                if (p.minc != winner_minc[q]) seen = p.minc < winner_minc[q];
-                else if (is_new != (won_new[q] != 0)) seen = !is_new;       // older representatives first
-                else seen = p.r <= member_of[q];
-            }
-            if (seen) {
+            const unsigned long long key = pair_key(p, is_new);
+            // the one-by-one pass examines candidates in key order up to and including the winner
+            if (status[q] == ST_REP || key <= winner_key[q]) {
                 S.filter_pairs++;
                 if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
                     S.aligned_pairs++;
                     S.aligned_rep_len += len2;
-                    S.dp_cells += (uint64_t)h_len[p.q] * (uint64_t)(p.band_right - p.band_left + 1);
+                    S.dp_cells += (uint64_t)h_len[k] * (uint64_t)(p.band_right - p.band_left + 1);
                 }
-                if ((p.flags & F_ACCEPT) && status[q] == ST_MEMBER && p.minc == winner_minc[q] &&
-                    is_new == (won_new[q] != 0) && p.r == member_of[q])
-                    iden_of[p.q] = p.iden;
+                if ((p.flags & F_ACCEPT) && status[q] == ST_MEMBER && key == winner_key[q]) iden_of[k] = p.iden;
             }
             return true;
         };
@@ -1416,7 +1536,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     unsigned long long visits_table = 0;
     PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
-    S.posting_visits = visits_table;
+    S.posting_visits = visits_table + visits_rc;
     S.reserved[0] = gpu_pairs; S.reserved[1] = gpu_aligned; S.reserved[2] = gpu_aligned_bytes;
     S.n_clusters = rep_seq.size();
 
@@ -1428,6 +1548,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         out_cluster[o] = c;
         out_member[o] = (int32_t)members[c]++;
         out_identity[o] = iden_of[k] >= 0 ? (float)iden_of[k] / (float)h_len[k] : 0.f;
+        if (out_strand) out_strand[o] = iden_of[k] >= 0 ? strand_of[k] : 0;
     }
     if (out_n_clusters) *out_n_clusters = (uint32_t)rep_seq.size();
     if (stats) *stats = S;

@@ -124,3 +124,42 @@ def pancore_matrix(n_genes=150000, n_genomes=400, seed=1):
         cols.append(c)
         have += m.shape[0]
     return (np.concatenate(rows).astype(np.int32), np.concatenate(cols).astype(np.int32), int(n_genes))
+
+
+def _revcomp(b):
+    return b[::-1].translate(bytes.maketrans(b'ACGT', b'TGCA'))
+
+
+def noncoding_set(n_genomes=400, seed=5, n_trna=60, rrna_lengths=(120, 1500, 2900), copies_rrna=3):
+    """Synthetic non-coding feature set of SURVEY §8d (config 5): per genome ~90 features --
+    tRNA-like families (74-90 nt) and rRNA-like ones (120 / 1,500 / 2,900 nt) -- each copy
+    0-10 % diverged from its ancestor, about half of them given on the reverse strand, a few
+    with N. Returns the exact-deduplicated (residues uint8 ASCII, offsets uint64, n_raw)."""
+    rng = np.random.default_rng(seed)
+    nt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    fams = [nt[rng.integers(0, 4, int(rng.integers(74, 91)))] for _ in range(n_trna)]
+    fams += [nt[rng.integers(0, 4, L)] for L in rrna_lengths for _ in range(copies_rrna)]
+    seen, chunks, lens, n_raw = set(), [], [], 0
+    for g in range(n_genomes):
+        for f, anc in enumerate(fams):
+            copies = 1 if f < n_trna else int(rng.integers(1, 4))
+            for _ in range(copies):
+                s = anc.copy()
+                div = rng.uniform(0.0, 0.10) if rng.random() < 0.7 else 0.0
+                k = int(div * s.size)
+                if k:
+                    pos = rng.choice(s.size, size=k, replace=False)
+                    s[pos] = nt[rng.integers(0, 4, k)]
+                if rng.random() < 0.02:
+                    s[int(rng.integers(0, s.size))] = ord('N')
+                b = s.tobytes()
+                if rng.random() < 0.5:
+                    b = _revcomp(b)
+                n_raw += 1
+                if b not in seen:
+                    seen.add(b)
+                    chunks.append(b)
+                    lens.append(len(b))
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(np.asarray(lens, dtype=np.uint64), out=offsets[1:])
+    return np.frombuffer(b''.join(chunks), dtype=np.uint8), offsets, n_raw

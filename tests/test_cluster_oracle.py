@@ -132,3 +132,57 @@ def test_clstr_grammar(tmp_path):
     cluster.write_clstr(path, ['h0', 'h1', 'h2'], np.diff(off.astype(np.int64)), cl, mem, iden, strand)
     assert open(path).read() == ('>Cluster 0\n0\t120aa, >h0... *\n1\t120aa, >h1... at 95.00%\n'
                                  '>Cluster 1\n0\t60aa, >h2... *\n')
+
+
+# ---- nucleotide rules (cd-hit-est restatement; parity unpinned) -------------
+def nt_params(**kw):
+    args = {'-n': 5, '-c': 0.8}
+    args.update(kw)
+    return cluster.params_from_cdhit_args(args, 'nt')
+
+
+def rand_nt(rng, n):
+    return ''.join(rng.choice(list('ACGT'), size=n))
+
+
+def revcomp(s):
+    return s[::-1].translate(str.maketrans('ACGTN', 'TGCAN'))
+
+
+def test_nt_reverse_strand_joins_with_minus():
+    rng = np.random.default_rng(21)
+    a, b = rand_nt(rng, 300), rand_nt(rng, 200)
+    seqs = [a, revcomp(a[:280]), b, b[:190], revcomp(a)[5:250]]
+    res, off = pack(seqs)
+    cl, mem, iden, strand, nc, st = oracle.cluster_greedy(res, off, nt_params())
+    assert nc == 2 and cl.tolist() == [0, 0, 1, 1, 0]
+    assert strand.tolist() == [0, 1, 0, 0, 1]
+    assert iden[1] == 1.0 and iden[3] == 1.0
+    p1 = nt_params(**{'-r': 0})                       # one strand only: the reverse copies cluster among themselves
+    cl1, _, _, strand1, nc1, _ = oracle.cluster_greedy(res, off, p1)
+    assert nc1 == 3 and not strand1.any()               # {a}, {rc(a[:280]), rc(a)[5:250]}, {b, b[:190]}
+
+
+def test_nt_threshold_and_n_handling():
+    rng = np.random.default_rng(22)
+    a = rand_nt(rng, 200)
+    def sub(s, k):                                    # a block of k N's: N never equals a base of the representative
+        return s[:60] + 'N' * k + s[60 + k:]
+    ok, bad = sub(a[:180], 36), sub(a[:180], 37)      # 144/180 = 0.80 and 143/180
+    withn = a[:100] + 'N' + a[101:190]                # one N: still one mismatch only
+    res, off = pack([a, ok, bad, withn, 'ACGTACGTAC'])
+    cl, mem, iden, strand, nc, st = oracle.cluster_greedy(res, off, nt_params())
+    assert cl[4] == -1                                # <= 10 nt discarded
+    assert cl[0] == cl[1] == cl[3] == 0 and cl[2] != 0
+    assert iden[1] == np.float32(144) / np.float32(180)
+    assert iden[3] == np.float32(189) / np.float32(190)
+
+
+def test_nt_clstr_grammar(tmp_path):
+    rng = np.random.default_rng(23)
+    a = rand_nt(rng, 120)
+    res, off = pack([a, revcomp(a)[:110]])
+    cl, mem, iden, strand, nc, _ = oracle.cluster_greedy(res, off, nt_params())
+    path = str(tmp_path / 'x.clstr')
+    cluster.write_clstr(path, ['h0', 'h1'], np.diff(off.astype(np.int64)), cl, mem, iden, strand, nucleotide=True)
+    assert open(path).read() == '>Cluster 0\n0\t120nt, >h0... *\n1\t110nt, >h1... at -/100.00%\n'

@@ -105,3 +105,77 @@ def test_build_cds_pangenome_end_to_end(tmp_path, gpu_ctx):
     want = oracle.cluster_greedy(res, off, params())
     assert len(dfg.index) == want[4]
     assert len(dfa.index) == int((want[0] >= 0).sum())
+
+
+# ---- K2: nucleotide rules (cd-hit-est), both strands ---------------------------------------------
+from test_cluster_oracle import nt_params, rand_nt, revcomp   # noqa: E402
+
+
+def test_nt_matches_oracle_on_synthetic_noncoding_set(gpu_ctx):
+    res, off, n_raw = synth.noncoding_set(n_genomes=40, seed=5)
+    for args in ({}, {'-r': 0}, {'-c': 0.9, '-n': 8}, {'-c': 0.97, '-n': 10}):
+        p = nt_params(**args)
+        assert_same_nt(gpu_ctx.cluster_greedy(res, off, p), oracle.cluster_greedy(res, off, p), args)
+
+
+def assert_same_nt(got, want, tag=''):
+    for g, w, name in zip(got[:4], want[:4], ('cluster', 'member', 'identity', 'strand')):
+        assert np.array_equal(g, w), '%s %s differs at %s' % (tag, name, np.flatnonzero(g != w)[:10])
+    assert got[4] == want[4]
+    gs, ws = dict(got[5]), dict(want[5])
+    for d in (gs, ws):
+        d.pop('sweeps'), d.pop('gpu')
+    assert gs == ws, tag
+
+
+def test_nt_edge_cases(gpu_ctx):
+    rng = np.random.default_rng(31)
+    a, b = rand_nt(rng, 400), rand_nt(rng, 1500)
+    cases = {
+        'strands': [a, revcomp(a[:380]), b, revcomp(b)[3:], b[:1400], revcomp(a)[5:250]],
+        'with N': [a, a[:100] + 'NNN' + a[103:390], 'N' * 50 + a[50:300], revcomp(a[:200] + 'N' + a[201:350])],
+        'low complexity': ['A' * 200, 'AC' * 100, 'T' * 180, 'ACGT' * 60, 'GT' * 90],
+        'short and ragged': [rand_nt(rng, n) for n in (11, 12, 74, 90, 10, 3000, 11)],
+        'lower case / U': [a, a.lower(), a.replace('T', 'U')],
+        'palindrome': [a[:60] + revcomp(a[:60]), revcomp(a[:60] + revcomp(a[:60]))],
+    }
+    p = nt_params()
+    for name, seqs in cases.items():
+        res, off = pack(seqs)
+        assert_same_nt(gpu_ctx.cluster_greedy(res, off, p), oracle.cluster_greedy(res, off, p), name)
+
+
+def test_nt_more_queries_than_one_sweep(gpu_ctx):
+    res, off, _ = synth.noncoding_set(n_genomes=120, seed=9)
+    assert off.size - 1 > 2 * 2048          # each query takes two batch slots: 2048 queries per sweep
+    p = nt_params()
+    got = gpu_ctx.cluster_greedy(res, off, p)
+    assert got[5]['sweeps'] >= 3
+    assert_same_nt(got, oracle.cluster_greedy(res, off, p))
+
+
+def test_build_noncoding_pangenome_end_to_end(tmp_path, gpu_ctx, golden_dir):
+    """GFF+FNA -> derived/*_noncoding.fna -> nucleotide clustering on the GPU -> tables; file
+    names per the reference (pangenome.py:259-307); extraction checked against its fixture."""
+    import filecmp
+    import os
+    import shutil
+    src = os.path.join(golden_dir, 'noncoding', 'in')
+    gdir = tmp_path / 'genomes'
+    shutil.copytree(src, gdir)
+    pairs = sorted(pangenome.find_matching_genome_files(str(gdir), str(gdir)))
+    assert [os.path.basename(g) for g, f in pairs] == ['n1.gff', 'n2.gff']
+    out = tmp_path / 'out'
+    out.mkdir()
+    dfa, dfg = pangenome.build_noncoding_pangenome(pairs, str(out), name='NC')
+    for g in ('n1', 'n2'):
+        assert filecmp.cmp(str(gdir / 'derived' / (g + '_noncoding.fna')),
+                           os.path.join(golden_dir, 'noncoding', 'expected', g + '_noncoding.fna'), shallow=False)
+    for f in ('NC_noncoding_nr.fna', 'NC_noncoding_nr.fna.cdhit.clstr', 'NC_noncoding_allele_names.tsv',
+              'NC_noncoding_redundant_headers.tsv', 'NC_noncoding_missing_headers.txt',
+              'NC_strain_by_noncoding_allele.npz', 'NC_strain_by_noncoding_gene.npz',
+              'NC_strain_by_noncoding_gene.npz.labels.txt'):
+        assert (out / f).exists(), f
+    assert list(dfg.columns) == ['n1', 'n2']            # '_noncoding' stripped from the column labels (:292-293)
+    assert all(x.startswith('NC_T') for x in dfg.index)
+    assert 'nt, >' in open(out / 'NC_noncoding_nr.fna.cdhit.clstr').read()
