@@ -284,7 +284,10 @@ __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t 
 //               key can still beat the query's current best.
 //   MODE_BLOCK  table = the current block of still-unassigned members; only later members of
 //               the same block are compared (the block is then resolved in order on the host).
-enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2 };
+//   MODE_FLAG   table = every still-unassigned member of the sweep; nothing is emitted, only
+//               flag_out[q] = 1 for unassigned members that have an earlier candidate among
+//               them. A member without one is certainly a new representative.
+enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2, MODE_FLAG = 3 };
 constexpr unsigned long long kNoBest = ~0ull;
 constexpr uint32_t kNewBit = 0x80000000u;
 
@@ -303,7 +306,8 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                                                    Pair *__restrict__ pairs, uint32_t *__restrict__ n_pairs,
                                                    uint32_t pair_cap,
                                                    unsigned long long *__restrict__ visits,
-                                                   unsigned long long *__restrict__ rc_visits) {
+                                                   unsigned long long *__restrict__ rc_visits,
+                                                   uint8_t *__restrict__ flag_out) {
     __shared__ uint32_t cnt[kBatchCap];
     __shared__ uint32_t minc[kBatchCap];
     __shared__ uint32_t vis[NT ? kBatchCap : 1];
@@ -327,17 +331,23 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                 if (MODE != MODE_TABLE && b0 + (q >= nbq ? q - nbq : q) <= k) continue;  // only queries after the representative
                 atomicAdd(&cnt[q], m < mq ? m : mq);
                 atomicMin(&minc[q], code);
+                if (MODE == MODE_BLOCK || MODE == MODE_FLAG) continue;  // visits are counted by TABLE / NEW passes
                 if (NT && q >= nbq) atomicAdd(&vis[q], 1u);  // reverse strand: attributed to the query
                 else ++my_visits;
             }
         }
-        if (MODE != MODE_BLOCK && my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
+        if (my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
         __syncthreads();
         for (uint32_t q = threadIdx.x; q < nb; q += 256) {
             const uint32_t c = cnt[q];
             const uint32_t ql = q >= nbq ? q - nbq : q;  // the query's local index; q >= nbq = reverse strand
-            if (NT && MODE != MODE_BLOCK && q >= nbq && vis[q]) atomicAdd(&rc_visits[ql], (unsigned long long)vis[q]);
+            if (NT && (MODE == MODE_TABLE || MODE == MODE_NEW) && q >= nbq && vis[q])
+                atomicAdd(&rc_visits[ql], (unsigned long long)vis[q]);
             if (c == 0u || (int32_t)c < req_aan[b0 + ql]) continue;
+            if (MODE == MODE_FLAG) {
+                if (qflag[ql]) flag_out[ql] = 1;  // an unassigned member with an earlier unassigned candidate
+                continue;
+            }
             if (MODE == MODE_NEW) {
                 if (qflag[ql]) continue;  // resolved inside a block already
                 const unsigned long long bo = best[ql];
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
             }
         }
         __syncthreads();
-        if (MODE != MODE_BLOCK && threadIdx.x == 0 && wg_visits) atomicAdd(visits, wg_visits);
+        if ((MODE == MODE_TABLE || MODE == MODE_NEW) && threadIdx.x == 0 && wg_visits) atomicAdd(visits, wg_visits);
     }
 }
 
@@ -394,6 +404,29 @@ __global__ __launch_bounds__(1024) void select_block_kernel(const unsigned long 
         ++rank;
     }
     if (tid == 1023) { counters[0] = part[tid] < block_cap ? part[tid] : block_cap; counters[1] = part[tid]; }
+}
+
+// The sweep's still-unassigned members (not final, no accepted representative): list + flags.
+__global__ __launch_bounds__(256) void list_open_kernel(const unsigned long long *__restrict__ best,
+                                                       const uint8_t *__restrict__ done, uint32_t b0, uint32_t nb,
+                                                       uint32_t *__restrict__ ulist, uint8_t *__restrict__ is_open,
+                                                       uint32_t *__restrict__ n_open) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nb) return;
+    const bool open = !done[q] && best[q] == kNoBest;
+    is_open[q] = open;
+    if (open) ulist[atomicAdd(n_open, 1u)] = b0 + q;
+}
+// Unassigned members without an earlier unassigned candidate are new representatives for
+// certain: list them (any order; they are numbered by sequence order later) and retire them.
+__global__ __launch_bounds__(256) void select_certain_kernel(const uint8_t *__restrict__ is_open,
+                                                            const uint8_t *__restrict__ has_cand,
+                                                            uint8_t *__restrict__ done, uint32_t b0, uint32_t nb,
+                                                            uint32_t *__restrict__ list, uint32_t *__restrict__ n_list) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nb || !is_open[q] || has_cand[q]) return;
+    done[q] = 1;
+    list[atomicAdd(n_list, 1u)] = b0 + q;
 }
 
 // block members are final once the host has walked the block
@@ -1255,7 +1288,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 kern<<<std::min(n_reps, 4096u), 256, 0, st>>>(
                     DS, d_rep_seq.as<uint32_t>(), nullptr, n_reps, b0, ns, nb, d_bi_off.as<uint32_t>(),
                     d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, nullptr, d_pairsA.as<Pair>(), d_nA,
-                    pair_cap, d_visits.as<unsigned long long>(), d_rcvis);
+                    pair_cap, d_visits.as<unsigned long long>(), d_rcvis, nullptr);
             }
             LAUNCH_CHECK();
             {
@@ -1270,6 +1303,54 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // only, so pair work stays close to what the one-by-one pass would do.
         for (uint32_t q = 0; q < nb; ++q) status[q] = ST_OPEN;
         uint32_t new_off = 0;  // new representatives of this sweep so far (staging offset)
+        // later queries against a list of new representatives already staged at d_new (on the device)
+        auto new_rep_pass = [&](const uint32_t *d_new, uint32_t nr) -> int {
+            snapshot_kernel<<<1, 1, 0, st>>>(d_nN, d_nN0);
+            {
+                ProfScope prof(ctx, "count_kernel<new>", st);
+                auto kern = nt ? count_kernel<MODE_NEW, true> : count_kernel<MODE_NEW, false>;
+                kern<<<nr, 256, 0, st>>>(DS, d_new, nullptr, nr, b0, ns, nb, d_bi_off.as<uint32_t>(),
+                                         d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done,
+                                         d_pairsN.as<Pair>(), d_nN, pair_cap, d_visits.as<unsigned long long>(),
+                                         d_rcvis, nullptr);
+            }
+            LAUNCH_CHECK();
+            const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, b0, 0};
+            return evaluate(nullptr, d_pairsN.as<Pair>(), selN, d_best, kNewBit, 0);
+        };
+        // Discovery: among all still-unassigned members, those without an earlier unassigned
+        // candidate are certain new representatives (typically the first member of every family
+        // that appears in this sweep). They are confirmed in one step, and the pass against
+        // them assigns most of the remaining members before any block is formed.
+        {
+            PGX_HIP(hipMemsetAsync(d_blk, 0, 8, st));            // counters [4] open, [5] certain
+            PGX_HIP(hipMemsetAsync(d_hascand, 0, kBatchCap, st));
+            list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_blk_list.as<uint32_t>(),
+                                                               d_skip2, d_blk);
+            LAUNCH_CHECK();
+            {
+                ProfScope prof(ctx, "count_kernel<flag>", st);
+                auto kern = nt ? count_kernel<MODE_FLAG, true> : count_kernel<MODE_FLAG, false>;
+                kern<<<std::min(nb, 4096u), 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb,
+                                                          d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
+                                                          d_aan.as<int32_t>(), nullptr, d_skip2, nullptr, nullptr, 0,
+                                                          nullptr, d_rcvis, d_hascand);
+            }
+            LAUNCH_CHECK();
+            select_certain_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_skip2, d_hascand, d_done, b0, nb,
+                                                                    d_new_list.as<uint32_t>(), d_blk + 1);
+            LAUNCH_CHECK();
+            PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
+            PGX_HIP(hipMemcpyAsync(h_new.p, d_new_list.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+            PGX_HIP(spin_sync(st));
+            const uint32_t n_certain = h_cnt.p[5];
+            for (uint32_t i = 0; i < n_certain; ++i) status[h_new.p[i] - b0] = ST_REP;
+            if (n_certain) {
+                int rc = new_rep_pass(d_new_list.as<uint32_t>(), n_certain);
+                if (rc) return rc;
+                new_off = n_certain;
+            }
+        }
         for (;;) {
             select_block_kernel<<<1, 1024, 0, st>>>(d_best, d_done, d_inblk, b0, nb, kBlockCap,
                                                     d_blk_list.as<uint32_t>(), d_blk);
@@ -1280,7 +1361,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 auto kern = nt ? count_kernel<MODE_BLOCK, true> : count_kernel<MODE_BLOCK, false>;
                 kern<<<kBlockCap, 256, 0, st>>>(
                     DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
-                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis);
+                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis, nullptr);
             }
             LAUNCH_CHECK();
             // A block member without an earlier in-block candidate is certainly a new
@@ -1421,22 +1502,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 std::copy(new_reps.begin(), new_reps.end(), h_new.p + new_off);
                 PGX_HIP(hipMemcpyAsync(d_new, h_new.p + new_off, (size_t)nr * 4, hipMemcpyHostToDevice, st));
                 new_off += nr;
-                snapshot_kernel<<<1, 1, 0, st>>>(d_nN, d_nN0);
                 retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb);
-                {
-                    ProfScope prof(ctx, "count_kernel<new>", st);
-                    auto kern = nt ? count_kernel<MODE_NEW, true> : count_kernel<MODE_NEW, false>;
-                    kern<<<nr, 256, 0, st>>>(
-                        DS, d_new, nullptr, nr, b0, ns, nb, d_bi_off.as<uint32_t>(),
-                        d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done, d_pairsN.as<Pair>(), d_nN,
-                        pair_cap, d_visits.as<unsigned long long>(), d_rcvis);
-                }
-                LAUNCH_CHECK();
-                {
-                    const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, b0, 0};
-                    int rc = evaluate(nullptr, d_pairsN.as<Pair>(), selN, d_best, kNewBit, 0);
-                    if (rc) return rc;
-                }
+                int rc = new_rep_pass(d_new, nr);
+                if (rc) return rc;
             }
             if (n_open == n_blk) break;  // that was the last block
         }
