@@ -330,8 +330,9 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                 const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
                 if (MODE != MODE_TABLE && b0 + (q >= nbq ? q - nbq : q) <= k) continue;  // only queries after the representative
                 atomicAdd(&cnt[q], m < mq ? m : mq);
+                if (MODE == MODE_FLAG) continue;  // only "has a candidate" is wanted: no key
                 atomicMin(&minc[q], code);
-                if (MODE == MODE_BLOCK || MODE == MODE_FLAG) continue;  // visits are counted by TABLE / NEW passes
+                if (MODE == MODE_BLOCK) continue;  // visits are counted by TABLE / NEW passes
                 if (NT && q >= nbq) atomicAdd(&vis[q], 1u);  // reverse strand: attributed to the query
                 else ++my_visits;
             }
