@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                                                    uint32_t pair_cap,
                                                    unsigned long long *__restrict__ visits,
                                                    unsigned long long *__restrict__ rc_visits,
-                                                   uint8_t *__restrict__ flag_out) {
+                                                   uint8_t *__restrict__ flag_out, uint32_t rep_base) {
     __shared__ uint32_t cnt[kBatchCap];
     __shared__ uint32_t minc[kBatchCap];
     __shared__ uint32_t vis[NT ? kBatchCap : 1];
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
             const uint32_t slot = atomicAdd(n_pairs, 1u);
             if (slot < pair_cap) {
                 Pair p;
-                p.q = slot_seq(S, b0, nbq, q); p.r = MODE == MODE_TABLE ? r : k; p.cnt = c; p.minc = minc[q];
+                p.q = slot_seq(S, b0, nbq, q); p.r = MODE == MODE_TABLE ? rep_base + r : k; p.cnt = c; p.minc = minc[q];
                 p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
                 pairs[slot] = p;
             }
@@ -1077,11 +1077,13 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
-        d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather;
+        d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather, d_bi_cnt2, d_bi_off2, d_bi_fill2, d_bi_ent2,
+        d_pairsA2, d_scan_tmp2, d_nA2;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
                          &d_bi_cnt, &d_bi_off, &d_bi_fill, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
-                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_list, &d_gather};
+                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_list, &d_gather,
+                         &d_bi_cnt2, &d_bi_off2, &d_bi_fill2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -1115,6 +1117,25 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(),
                                              (int)(n_codes + 1), st));
     PGX_HIP(d_scan_tmp.alloc(scan_bytes));
+    // Sweep pipelining (proteins): while sweep s resolves its members on the main stream, the
+    // side stream already builds the index of sweep s+1 and streams the representatives known
+    // so far against it; sweep s+1 then only adds the representatives created in sweep s.
+    const bool pipeline = !nt && n > sweep_cap;
+    PGX_HIP(d_nA2.alloc(64));
+    if (pipeline) {
+        PGX_HIP(d_bi_cnt2.alloc(((size_t)n_codes + 1) * 4));
+        PGX_HIP(d_bi_off2.alloc(((size_t)n_codes + 1) * 4));
+        PGX_HIP(d_bi_fill2.alloc((size_t)n_codes * 4));
+        PGX_HIP(d_bi_ent2.alloc((max_batch_words + 16) * 4));
+        PGX_HIP(d_pairsA2.alloc((size_t)pair_cap * sizeof(Pair)));
+        PGX_HIP(d_scan_tmp2.alloc(scan_bytes));
+    }
+    struct SweepBuf { uint32_t *bi_cnt, *bi_off, *bi_fill, *bi_ent; Pair *pairsA; uint32_t *nA; void *scan_tmp; };
+    SweepBuf sbuf[2] = {
+        {d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(), d_bi_fill.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
+         d_pairsA.as<Pair>(), d_nA2.as<uint32_t>(), d_scan_tmp.p},
+        {d_bi_cnt2.as<uint32_t>(), d_bi_off2.as<uint32_t>(), d_bi_fill2.as<uint32_t>(), d_bi_ent2.as<uint32_t>(),
+         d_pairsA2.as<Pair>(), d_nA2.as<uint32_t>() + 8, d_scan_tmp2.p}};
 
     PGX_HIP(d_order.alloc((size_t)n * 4));
     PGX_HIP(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1175,8 +1196,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(8)); PGX_HIP(h_blk.reserve(kBatchCap));
     PGX_HIP(h_new.reserve(kBatchCap)); PGX_HIP(hK.reserve(pair_cap_k)); PGX_HIP(hA.reserve(kPrefix)); PGX_HIP(hN.reserve(kPrefix));
     // device counters: [0] pairsA, [1] pairsN, [2] pairsK, [3] pairsN range start, [4] block size, [5] open members
-    uint32_t *d_nA = d_counters.as<uint32_t>(), *d_nN = d_nA + 1, *d_nK = d_nA + 2, *d_nN0 = d_nA + 3,
-             *d_blk = d_nA + 4;
+    uint32_t *d_nN = d_counters.as<uint32_t>() + 1, *d_nK = d_nN + 1, *d_nN0 = d_nN + 2, *d_blk = d_nN + 3;
+    uint32_t head_ready = 0xFFFFFFFFu, head_reps = 0;  // sweep whose head already runs on the side stream
+    Pinned<uint32_t> h_nA;
+    PGX_HIP(h_nA.reserve(4));
     unsigned long long *d_best = d_best_old.as<unsigned long long>(), *d_rcvis = d_best + kBatchCap;
     Pinned<unsigned long long> h_rcvis;
     PGX_HIP(h_rcvis.reserve(kBatchCap));
@@ -1228,6 +1251,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 pair_cap = (uint32_t)(need + need / 2);
                 PGX_HIP(d_pairsA.alloc((size_t)pair_cap * sizeof(Pair)));
                 PGX_HIP(d_pairsN.alloc((size_t)pair_cap * sizeof(Pair)));
+                sbuf[0].pairsA = d_pairsA.as<Pair>();
             }
         }
         S.sweeps++;
@@ -1236,29 +1260,65 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // the general (int64, one pair per wave) aligner is only needed when some pair of this
         // sweep cannot use the 16-lane fast path: query length + longest sequence, or the band
         const bool any_wide = P->band_width > 32 || (int)(h_len[b0] + max_len) > kA16MaxSum;
-        // index over the batch
-        PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));
-        PGX_HIP(hipMemsetAsync(d_bi_fill.p, 0, (size_t)n_codes * 4, st));
+        const uint32_t parity = (uint32_t)(S.sweeps & 1);
+        const SweepBuf &B = sbuf[pipeline ? parity : 0];
+        uint32_t *d_nA = B.nA;
+        // sweep head = index over the batch + the table pass against representatives [0, n_table);
+        // it only depends on the sweep's position, so it can run ahead on the side stream
+        auto sweep_head = [&](const SweepBuf &W, uint32_t hb0, uint32_t hnb, uint32_t hns, uint32_t n_table,
+                              hipStream_t hs) -> int {
+            PGX_HIP(hipMemsetAsync(W.bi_cnt, 0, ((size_t)n_codes + 1) * 4, hs));
+            PGX_HIP(hipMemsetAsync(W.bi_fill, 0, (size_t)n_codes * 4, hs));
+            PGX_HIP(hipMemsetAsync(W.nA, 0, 4, hs));
+            {
+                ProfScope prof(ctx, "index_hist_kernel", hs);
+                index_hist_kernel<<<hns, 256, 0, hs>>>(DS, hb0, hns, hnb, W.bi_cnt);
+            }
+            LAUNCH_CHECK();
+            {
+                ProfScope prof(ctx, "index_scan(hipcub)", hs);
+                size_t sb = scan_bytes;
+                PGX_HIP(hipcub::DeviceScan::ExclusiveSum(W.scan_tmp, sb, W.bi_cnt, W.bi_off, (int)(n_codes + 1), hs));
+            }
+            {
+                ProfScope prof(ctx, "index_scatter_kernel", hs);
+                index_scatter_kernel<<<hns, 256, 0, hs>>>(DS, hb0, hns, hnb, W.bi_off, W.bi_fill, W.bi_ent);
+            }
+            LAUNCH_CHECK();
+            if (n_table) {
+                ProfScope prof(ctx, "count_kernel<table>", hs);
+                auto kern = nt ? count_kernel<MODE_TABLE, true> : count_kernel<MODE_TABLE, false>;
+                // on the side stream leave room (LDS, wave slots) for the main stream's small kernels
+                kern<<<std::min(n_table, hs == st ? 4096u : 512u), 256, 0, hs>>>(
+                    DS, d_rep_seq.as<uint32_t>(), nullptr, n_table, hb0, hns, hnb, W.bi_off, W.bi_ent,
+                    d_aan.as<int32_t>(), nullptr, nullptr, W.pairsA, W.nA, pair_cap,
+                    d_visits.as<unsigned long long>(), d_rcvis, nullptr, 0u);
+                LAUNCH_CHECK();
+            }
+            return PGX_OK;
+        };
         PGX_HIP(hipMemsetAsync(d_counters.p, 0, 32, st));
         PGX_HIP(hipMemsetAsync(d_best, 0xFF, kBatchCap * 8, st));
         if (both) PGX_HIP(hipMemsetAsync(d_rcvis, 0, kBatchCap * 8, st));
         PGX_HIP(hipMemsetAsync(d_done, 0, 2 * kBatchCap, st));
-        {
-            ProfScope prof(ctx, "index_hist_kernel", st);
-            index_hist_kernel<<<ns, 256, 0, st>>>(DS, b0, ns, nb, d_bi_cnt.as<uint32_t>());
+        uint32_t n_pre = 0;  // representatives the head has already been through
+        if (head_ready == b0) {  // the previous sweep ran this head on the side stream
+            PGX_HIP(hipStreamWaitEvent(st, ctx->ev_side[parity], 0));
+            n_pre = head_reps;
+        } else {
+            int rc = sweep_head(B, b0, nb, ns, n_reps, st);
+            if (rc) return rc;
+            n_pre = n_reps;
         }
-        LAUNCH_CHECK();
-        {
-            ProfScope prof(ctx, "index_scan(hipcub)", st);
-            PGX_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp.p, scan_bytes, d_bi_cnt.as<uint32_t>(),
-                                                     d_bi_off.as<uint32_t>(), (int)(n_codes + 1), st));
+        if (n_reps > n_pre) {  // representatives created after the head was enqueued (the previous sweep's)
+            ProfScope prof(ctx, "count_kernel<table>", st);
+            auto kern = nt ? count_kernel<MODE_TABLE, true> : count_kernel<MODE_TABLE, false>;
+            kern<<<std::min(n_reps - n_pre, 4096u), 256, 0, st>>>(
+                DS, d_rep_seq.as<uint32_t>() + n_pre, nullptr, n_reps - n_pre, b0, ns, nb, B.bi_off, B.bi_ent,
+                d_aan.as<int32_t>(), nullptr, nullptr, B.pairsA, B.nA, pair_cap, d_visits.as<unsigned long long>(),
+                d_rcvis, nullptr, n_pre);
+            LAUNCH_CHECK();
         }
-        {
-            ProfScope prof(ctx, "index_scatter_kernel", st);
-            index_scatter_kernel<<<ns, 256, 0, st>>>(DS, b0, ns, nb, d_bi_off.as<uint32_t>(),
-                                                     d_bi_fill.as<uint32_t>(), d_bi_ent.as<uint32_t>());
-        }
-        LAUNCH_CHECK();
         // diag + align of a selection of pair records, enqueued on the stream
         auto evaluate = [&](const uint32_t *rep_map, Pair *pairs, const PairSel &sel, unsigned long long *best_arr,
                             uint32_t key_flag, uint32_t grid_hint) -> int {
@@ -1283,20 +1343,18 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         };
         // phase A: against the representatives that exist already (fully on the device)
         if (n_reps) {
-            {
-                ProfScope prof(ctx, "count_kernel<table>", st);
-                auto kern = nt ? count_kernel<MODE_TABLE, true> : count_kernel<MODE_TABLE, false>;
-                kern<<<std::min(n_reps, 4096u), 256, 0, st>>>(
-                    DS, d_rep_seq.as<uint32_t>(), nullptr, n_reps, b0, ns, nb, d_bi_off.as<uint32_t>(),
-                    d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), nullptr, nullptr, d_pairsA.as<Pair>(), d_nA,
-                    pair_cap, d_visits.as<unsigned long long>(), d_rcvis, nullptr);
-            }
-            LAUNCH_CHECK();
-            {
-                const PairSel selA{nullptr, d_nA, pair_cap, nullptr, 0, nullptr, b0, 0};
-                int rc = evaluate(d_rep_seq.as<uint32_t>(), d_pairsA.as<Pair>(), selA, d_best, 0u, 0);
-                if (rc) return rc;
-            }
+            const PairSel selA{nullptr, d_nA, pair_cap, nullptr, 0, nullptr, b0, 0};
+            int rc = evaluate(d_rep_seq.as<uint32_t>(), B.pairsA, selA, d_best, 0u, 0);
+            if (rc) return rc;
+        }
+        if (pipeline && b0 + sweep_cap < n) {  // next sweep's head, overlapping this sweep's phase B
+            const uint32_t hb0 = b0 + sweep_cap, hnb = std::min(sweep_cap, n - hb0);
+            PGX_HIP(hipEventRecord(ctx->ev_main, st));  // the representative list up to here is on the device
+            PGX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_main, 0));
+            int rc = sweep_head(sbuf[parity ^ 1], hb0, hnb, hnb, n_reps, ctx->stream2);
+            if (rc) return rc;
+            PGX_HIP(hipEventRecord(ctx->ev_side[parity ^ 1], ctx->stream2));
+            head_ready = hb0; head_reps = n_reps;
         }
         // phase B: members without a representative, one block at a time. A block is
         // resolved exactly (all its in-block pairs are aligned, then the host walks it in
@@ -1310,10 +1368,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             {
                 ProfScope prof(ctx, "count_kernel<new>", st);
                 auto kern = nt ? count_kernel<MODE_NEW, true> : count_kernel<MODE_NEW, false>;
-                kern<<<nr, 256, 0, st>>>(DS, d_new, nullptr, nr, b0, ns, nb, d_bi_off.as<uint32_t>(),
-                                         d_bi_ent.as<uint32_t>(), d_aan.as<int32_t>(), d_best, d_done,
+                kern<<<nr, 256, 0, st>>>(DS, d_new, nullptr, nr, b0, ns, nb, B.bi_off,
+                                         B.bi_ent, d_aan.as<int32_t>(), d_best, d_done,
                                          d_pairsN.as<Pair>(), d_nN, pair_cap, d_visits.as<unsigned long long>(),
-                                         d_rcvis, nullptr);
+                                         d_rcvis, nullptr, 0u);
             }
             LAUNCH_CHECK();
             const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, b0, 0};
@@ -1333,9 +1391,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 ProfScope prof(ctx, "count_kernel<flag>", st);
                 auto kern = nt ? count_kernel<MODE_FLAG, true> : count_kernel<MODE_FLAG, false>;
                 kern<<<std::min(nb, 4096u), 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb,
-                                                          d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
+                                                          B.bi_off, B.bi_ent,
                                                           d_aan.as<int32_t>(), nullptr, d_skip2, nullptr, nullptr, 0,
-                                                          nullptr, d_rcvis, d_hascand);
+                                                          nullptr, d_rcvis, d_hascand, 0u);
             }
             LAUNCH_CHECK();
             select_certain_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_skip2, d_hascand, d_done, b0, nb,
@@ -1361,8 +1419,8 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 ProfScope prof(ctx, "count_kernel<block>", st);
                 auto kern = nt ? count_kernel<MODE_BLOCK, true> : count_kernel<MODE_BLOCK, false>;
                 kern<<<kBlockCap, 256, 0, st>>>(
-                    DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
-                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis, nullptr);
+                    DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, B.bi_off, B.bi_ent,
+                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis, nullptr, 0u);
             }
             LAUNCH_CHECK();
             // A block member without an earlier in-block candidate is certainly a new
@@ -1391,9 +1449,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             PGX_HIP(hipMemcpyAsync(hK.p, d_pairsK.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
             PGX_HIP(spin_sync(st));
             const uint32_t n_blk = h_cnt.p[4], n_open = h_cnt.p[5], nK = h_cnt.p[2];
-            if (h_cnt.p[0] > pair_cap || h_cnt.p[1] > pair_cap || nK > pair_cap_k) {
-                pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u / %u) in sweep at %u",
-                              h_cnt.p[0], h_cnt.p[1], nK, b0);
+            if (h_cnt.p[1] > pair_cap || nK > pair_cap_k) {
+                pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u) in sweep at %u",
+                              h_cnt.p[1], nK, b0);
                 return PGX_ERR_CAPACITY;
             }
             if (n_blk == 0) break;
@@ -1513,10 +1571,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
         PGX_HIP(hipMemcpyAsync(h_best.p, d_best, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
         if (both) PGX_HIP(hipMemcpyAsync(h_rcvis.p, d_rcvis, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipMemcpyAsync(h_nA.p, d_nA, 4, hipMemcpyDeviceToHost, st));
+        PGX_HIP(hipMemcpyAsync(hA.p, B.pairsA, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
         PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
         PGX_HIP(spin_sync(st));
-        const uint32_t nA = h_cnt.p[0], nN = h_cnt.p[1];
+        const uint32_t nA = h_nA.p[0], nN = h_cnt.p[1];
         if (nA > pair_cap || nN > pair_cap) {
             pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u > %u) in sweep at %u",
                           nA, nN, pair_cap, b0);
@@ -1524,7 +1583,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         }
         if (nA > kPrefix || nN > kPrefix) {
             PGX_HIP(hA.reserve(nA)); PGX_HIP(hN.reserve(nN));  // (reserve keeps nothing: copy whole ranges again)
-            if (nA) PGX_HIP(hipMemcpyAsync(hA.p, d_pairsA.p, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
+            if (nA) PGX_HIP(hipMemcpyAsync(hA.p, B.pairsA, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
             if (nN) PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)nN * sizeof(Pair), hipMemcpyDeviceToHost, st));
             PGX_HIP(spin_sync(st));
         }

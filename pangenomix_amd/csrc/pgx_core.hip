@@ -112,6 +112,14 @@ int pgx_ctx_create(int device_id, pgx_ctx **out) {
     ctx->device_id = device_id;
     e = hipGetDeviceProperties(&ctx->prop, device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {  // side stream at the lowest priority: it only runs ahead into idle CUs
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_side[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_side[1], hipEventDisableTiming);
     if (e != hipSuccess) {
         pgx_set_error("pgx_ctx_create: %s", hipGetErrorString(e));
         delete ctx;
@@ -129,7 +137,11 @@ void pgx_ctx_destroy(pgx_ctx *ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &a : ctx->arena)
         if (a.first) (void)hipFree(a.first);
+    (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);
+    for (hipEvent_t e : ctx->ev_side) if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 

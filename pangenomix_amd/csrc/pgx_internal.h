@@ -23,6 +23,8 @@ struct ProfSlot {
 struct pgx_ctx {
     int device_id;
     hipStream_t stream;  // used by the host-pointer entry points
+    hipStream_t stream2; // side stream: next sweep's index + table pass overlap the current sweep
+    hipEvent_t ev_main = nullptr, ev_side[2] = {nullptr, nullptr};
     hipDeviceProp_t prop;
     bool profiling = false;
     std::vector<ProfSlot> prof;
