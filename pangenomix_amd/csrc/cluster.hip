@@ -290,6 +290,7 @@ __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t 
 enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2, MODE_FLAG = 3 };
 constexpr unsigned long long kNoBest = ~0ull;
 constexpr uint32_t kNewBit = 0x80000000u;
+constexpr uint32_t kLongMin = 16, kLongCap = 512;  // posting lists walked wave-cooperatively
 
 // NT adds per-query visit counters for the reverse-strand slots: the one-by-one pass only walks
 // a query's reverse-complement words when its forward strand found no representative, so
@@ -311,30 +312,47 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
     __shared__ uint32_t cnt[kBatchCap];
     __shared__ uint32_t minc[kBatchCap];
     __shared__ uint32_t vis[NT ? kBatchCap : 1];
+    // posting lists longer than kLongMin entries are queued and walked by whole waves with
+    // coalesced loads (members of one family share most words: their lists have hundreds of entries)
+    __shared__ uint32_t lq_lo[kLongCap], lq_meta[kLongCap], lq_code[kLongCap];
+    __shared__ uint32_t n_long;
     __shared__ unsigned long long wg_visits;
     const uint32_t ntable = d_ntable ? *d_ntable : ntable_host;
     for (uint32_t r = blockIdx.x; r < ntable; r += gridDim.x) {
         for (uint32_t q = threadIdx.x; q < nb; q += 256) { cnt[q] = 0u; minc[q] = kSentinel; if (NT) vis[q] = 0u; }
-        if (threadIdx.x == 0) wg_visits = 0ull;
+        if (threadIdx.x == 0) { wg_visits = 0ull; n_long = 0u; }
         __syncthreads();
         const uint32_t k = table[r];
         const uint64_t o = S.off[k];
         const uint32_t n = S.wcnt[k];
         uint32_t my_visits = 0;
+        auto visit = [&](uint32_t ent, uint32_t m, uint32_t code) {
+            const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
+            if (MODE != MODE_TABLE && b0 + (q >= nbq ? q - nbq : q) <= k) return;  // only queries after the representative
+            atomicAdd(&cnt[q], m < mq ? m : mq);
+            if (MODE == MODE_FLAG) return;  // only "has a candidate" is wanted: no key
+            atomicMin(&minc[q], code);
+            if (MODE == MODE_BLOCK) return;  // visits are counted by the TABLE / NEW passes
+            if (NT && q >= nbq) atomicAdd(&vis[q], 1u);  // reverse strand: attributed to the query
+            else ++my_visits;
+        };
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const uint32_t code = S.wcode[o + i];
             const uint32_t m = S.wmult[o + i];
             const uint32_t lo = bi_off[code], hi = bi_off[code + 1];
-            for (uint32_t e = lo; e < hi; ++e) {
-                const uint32_t ent = bi_ent[e];
-                const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
-                if (MODE != MODE_TABLE && b0 + (q >= nbq ? q - nbq : q) <= k) continue;  // only queries after the representative
-                atomicAdd(&cnt[q], m < mq ? m : mq);
-                if (MODE == MODE_FLAG) continue;  // only "has a candidate" is wanted: no key
-                atomicMin(&minc[q], code);
-                if (MODE == MODE_BLOCK) continue;  // visits are counted by TABLE / NEW passes
-                if (NT && q >= nbq) atomicAdd(&vis[q], 1u);  // reverse strand: attributed to the query
-                else ++my_visits;
+            if (hi - lo > kLongMin) {
+                const uint32_t slot = atomicAdd(&n_long, 1u);
+                if (slot < kLongCap) { lq_lo[slot] = lo; lq_meta[slot] = ((hi - lo) << 16) | m; lq_code[slot] = code; continue; }
+            }
+            for (uint32_t e = lo; e < hi; ++e) visit(bi_ent[e], m, code);
+        }
+        __syncthreads();
+        {
+            const uint32_t nl = n_long < kLongCap ? n_long : kLongCap;
+            const uint32_t lane = threadIdx.x & 63u;
+            for (uint32_t w = threadIdx.x >> 6; w < nl; w += 4) {
+                const uint32_t lo = lq_lo[w], len = lq_meta[w] >> 16, m = lq_meta[w] & 0xFFFFu, code = lq_code[w];
+                for (uint32_t e = lane; e < len; e += 64) visit(bi_ent[lo + e], m, code);
             }
         }
         if (my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
