@@ -39,7 +39,7 @@ class ClusterStats(C.Structure):
     def as_dict(self):
         d = {n: int(getattr(self, n)) for n in STAT_FIELDS}
         d['gpu'] = {'pairs': int(self.reserved[0]), 'aligned': int(self.reserved[1]),
-                    'aligned_bytes': int(self.reserved[2])}
+                    'aligned_bytes': int(self.reserved[2]), 'table_stream_words': int(self.reserved[3])}
         return d
 
 

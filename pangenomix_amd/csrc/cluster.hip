@@ -9,23 +9,27 @@
 // Acceptance A(q, r) is a pure function of the pair, so the GPU evaluates pairs in bulk
 // and only the final "first accepted in key order" selection follows the greedy order.
 //
-// One SWEEP handles a batch of up to kBatchCap consecutive queries:
-//   index   direct-address CSR over the batch's distinct (word, query, multiplicity) entries
+// One SWEEP handles up to kBatchCap batch slots (consecutive queries; with nucleotides and both
+// strands each query takes a second slot for its reverse complement):
+//   index   direct-address CSR over the batch's distinct (word, slot, multiplicity) entries
 //           (counting sort: histogram -> exclusive scan -> scatter)
-//   count   one workgroup per representative streams the representative's distinct-word
-//           list from HBM (coalesced), probes the CSR, and accumulates the short-word
-//           counters min(mult_q, mult_r) and the smallest shared code for all batch queries
-//           in LDS; pairs reaching required_aan are emitted
-//   diag    one wave per pair: 2-mer diagonal histogram in LDS, best band window
-//   align   one wave per pair: banded DP, one band column per lane, anti-diagonal
-//           wavefront, neighbours' cells exchanged with wave shuffles, identity carried
-//           along the best path (no traceback matrix)
-//   phase A = batch vs representatives that existed before the sweep, fully on device,
-//   phase B = batch vs the batch's own still-unassigned members; the in-order resolution
-//   of phase B runs on the host in rounds that only align edges to confirmed representatives.
+//   count   one workgroup per representative streams the representative's distinct-word list
+//           from HBM (coalesced), probes the CSR, and accumulates the short-word counters
+//           min(mult_q, mult_r) and the smallest shared code for all batch slots in LDS; long
+//           posting lists are walked by whole waves; pairs reaching required_aan are emitted
+//   diag    one wave per pair: k-mer diagonal histogram in LDS, best band window
+//   align   banded DP on the anti-diagonal wavefront: four pairs per wave (one per DPP row of
+//           16 lanes, two band columns per lane, row_shr/row_shl exchanges, int32 scores),
+//           identity carried along the best path (no traceback matrix)
+//   phase A = batch vs representatives that existed before the sweep, fully on the device;
+//             its index + table pass run one sweep ahead on a side stream
+//   phase B = members left without a representative: (1) those with no earlier unassigned
+//             candidate are certain new representatives and are confirmed at once, (2) the rest
+//             is resolved block-wise, in order, exactly; every later query is then compared
+//             only with the new representatives.
 //
-// HBM layout: residues 1 byte/residue in sorted order; word lists (u32 code, u16 mult) at
-// the same offsets as the residues; everything stays resident for the whole call.
+// HBM layout: residues 1 byte/residue in sorted order (reverse complements appended as virtual
+// sequences); word lists (u32 code, u16 mult) at the same offsets; grow-only per-context workspace.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -953,12 +957,31 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
 namespace {
 
 template <typename T>
-struct Pinned {  // page-locked host staging buffer
+struct Pinned {  // page-locked host staging buffer; bound to a context slot it outlives the call
     T *p = nullptr;
     size_t cap = 0;
-    ~Pinned() { if (p) (void)hipHostFree(p); }
+    pgx_ctx *ctx = nullptr;
+    int slot = -1;
+    ~Pinned() { if (p && !ctx) (void)hipHostFree(p); }
+    void bind(pgx_ctx *c, int s) { ctx = c; slot = s; }
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
+        if (ctx) {
+            if ((int)ctx->host_arena.size() <= slot) ctx->host_arena.resize((size_t)slot + 1, {nullptr, 0});
+            auto &a = ctx->host_arena[(size_t)slot];
+            const size_t bytes = n * sizeof(T);
+            if (!a.first || a.second < bytes) {
+                if (a.first) (void)hipHostFree(a.first);
+                a = {nullptr, 0};
+                const size_t want = bytes + bytes / 2 + 4096;
+                hipError_t e = hipHostMalloc(&a.first, want, hipHostMallocDefault);
+                if (e != hipSuccess) return e;
+                a.second = want;
+            }
+            p = static_cast<T *>(a.first);
+            cap = a.second / sizeof(T);
+            return hipSuccess;
+        }
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = n + n / 2 + 1024;
@@ -1209,6 +1232,8 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     Pinned<unsigned long long> h_best;
     Pinned<uint32_t> h_cnt, h_blk;
     Pinned<uint32_t> h_new, h_rep_stage[2];
+    hA.bind(ctx, 0); hN.bind(ctx, 1); hK.bind(ctx, 2); h_best.bind(ctx, 3); h_cnt.bind(ctx, 4); h_blk.bind(ctx, 5);
+    h_new.bind(ctx, 6); h_rep_stage[0].bind(ctx, 7); h_rep_stage[1].bind(ctx, 8);
     PGX_HIP(h_rep_stage[0].reserve(kBatchCap)); PGX_HIP(h_rep_stage[1].reserve(kBatchCap));
     constexpr uint32_t kPrefix = 4096;  // pairs copied back together with the counters
     PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(8)); PGX_HIP(h_blk.reserve(kBatchCap));
@@ -1217,9 +1242,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     uint32_t *d_nN = d_counters.as<uint32_t>() + 1, *d_nK = d_nN + 1, *d_nN0 = d_nN + 2, *d_blk = d_nN + 3;
     uint32_t head_ready = 0xFFFFFFFFu, head_reps = 0;  // sweep whose head already runs on the side stream
     Pinned<uint32_t> h_nA;
+    h_nA.bind(ctx, 10);
     PGX_HIP(h_nA.reserve(4));
     unsigned long long *d_best = d_best_old.as<unsigned long long>(), *d_rcvis = d_best + kBatchCap;
     Pinned<unsigned long long> h_rcvis;
+    h_rcvis.bind(ctx, 9);
     PGX_HIP(h_rcvis.reserve(kBatchCap));
     uint64_t visits_rc = 0;
     uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + kBatchCap;
@@ -1234,12 +1261,13 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     };
     Pinned<uint32_t> h_list;
     Pinned<Pair> h_gather;
+    h_list.bind(ctx, 11); h_gather.bind(ctx, 12);
     PGX_HIP(h_list.reserve(pair_cap_k)); PGX_HIP(h_gather.reserve(pair_cap_k));
     uint8_t *d_hascand = d_flags.as<uint8_t>() + 2 * kBatchCap, *d_accepted = d_hascand + kBatchCap,
             *d_skip2 = d_accepted + kBatchCap;
     uint64_t n_rounds = 0;
 
-    uint64_t gpu_pairs = 0, gpu_aligned = 0, gpu_aligned_bytes = 0;  // actual device work (reserved stats slots)
+    uint64_t gpu_pairs = 0, gpu_aligned = 0, gpu_aligned_bytes = 0, table_stream_words = 0;  // actual device work (reserved stats slots)
     auto account = [&](const Pair *pp, uint32_t cnt, bool via_rep) {
         for (uint32_t i = 0; i < cnt; ++i) {
             ++gpu_pairs;
@@ -1257,6 +1285,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         const uint32_t nb = std::min(sweep_cap, n - b0);  // queries of this sweep
         const uint32_t ns = both ? 2 * nb : nb;           // batch slots: + one per reverse complement
         const uint32_t n_reps = (uint32_t)rep_seq.size();
+        table_stream_words += S.rep_words;  // every sweep streams the word lists of all representatives so far
         if (nt) {  // at cd-hit-est's -n 5 -c 0.8 one shared word is enough: size the pair buffers for all pairs
             const uint64_t need = (uint64_t)ns * ((uint64_t)n_reps + nb) + 1024;
             if (need > (400ull << 20)) {
@@ -1684,6 +1713,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(hipStreamSynchronize(st));
     S.posting_visits = visits_table + visits_rc;
     S.reserved[0] = gpu_pairs; S.reserved[1] = gpu_aligned; S.reserved[2] = gpu_aligned_bytes;
+    S.reserved[3] = table_stream_words;
     S.n_clusters = rep_seq.size();
 
     // ---- outputs in the caller's order; member numbers follow the sorted order (A.3) ------

@@ -137,6 +137,8 @@ void pgx_ctx_destroy(pgx_ctx *ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &a : ctx->arena)
         if (a.first) (void)hipFree(a.first);
+    for (auto &a : ctx->host_arena)
+        if (a.first) (void)hipHostFree(a.first);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);

@@ -31,6 +31,8 @@ struct pgx_ctx {
     std::vector<hipEvent_t> event_pool;
     // grow-only device workspace, reused by successive calls on this context (slot -> buffer)
     std::vector<std::pair<void *, size_t>> arena;
+    // grow-only page-locked host staging buffers (slot -> buffer), same idea
+    std::vector<std::pair<void *, size_t>> host_arena;
 };
 
 // RAII bracket: records start/stop events on `stream` when profiling is enabled.

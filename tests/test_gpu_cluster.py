@@ -179,3 +179,26 @@ def test_build_noncoding_pangenome_end_to_end(tmp_path, gpu_ctx, golden_dir):
     assert list(dfg.columns) == ['n1', 'n2']            # '_noncoding' stripped from the column labels (:292-293)
     assert all(x.startswith('NC_T') for x in dfg.index)
     assert 'nt, >' in open(out / 'NC_noncoding_nr.fna.cdhit.clstr').read()
+
+
+# ---- BASELINE-size checks ---------------------------------------------------------------------
+def test_cfg2s_full_parity_and_idempotence(gpu_ctx):
+    """BASELINE configs[1] size (50 genomes x 4,500 CDS synthetic, ~165k non-redundant proteins):
+    full bit-exact comparison with the oracle, plus the size-independent property that the
+    representatives alone re-cluster into singletons in the same order (idempotence)."""
+    res, off, _ = synth.protein_set('cfg-2s').nr_arrays()
+    p = params()
+    got = gpu_ctx.cluster_greedy(res, off, p)
+    assert_same(got, oracle.cluster_greedy(res, off, p))
+    cl, mem, iden = got[0], got[1], got[2]
+    lens = np.diff(off.astype(np.int64))
+    assert (iden[mem > 0] >= np.float32(0.8)).all() and (iden[mem == 0] == 0).all()
+    assert ((lens <= 10) == (cl < 0)).all()
+    reps = np.flatnonzero(mem == 0)
+    reps = reps[np.argsort(cl[reps])]                      # creation order = descending length, stable
+    rres = np.concatenate([res[off[i]:off[i + 1]] for i in reps])
+    roff = np.zeros(reps.size + 1, dtype=np.uint64)
+    np.cumsum(lens[reps].astype(np.uint64), out=roff[1:])
+    again = gpu_ctx.cluster_greedy(rres, roff, p)
+    assert again[4] == reps.size and (again[1] == 0).all()
+    assert np.array_equal(again[0], np.arange(reps.size, dtype=np.int32))

@@ -15,6 +15,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -24,8 +25,10 @@ WIDE_READ = {'pan_core_sweep_kernel'}          # 16 B / lane streaming reads
 def short(name):
     name = name.replace('(anonymous namespace)::', '')
     name = name.split('(')[0].replace('void ', '').strip()
-    return {'count_kernel<0>': 'count_kernel<table>', 'count_kernel<1>': 'count_kernel<new>',
-            'count_kernel<2>': 'count_kernel<block>'}.get(name, name)
+    m = re.match(r'count_kernel<(\d)(, (true|false))?>', name)
+    if m:
+        return 'count_kernel<%s>' % ('table', 'new', 'block', 'flag')[int(m.group(1))]
+    return name
 
 
 def load(directory, counter):
