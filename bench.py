@@ -33,9 +33,9 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cluster_algorithmic_bytes(st, bits=8):
-    """B_cluster of SURVEY §8d from the sequential-rule counters (b = bits per residue as
-    stored: 8 in this round's layout, 5 once the packed layout lands)."""
+def cluster_algorithmic_bytes(st, bits=5):
+    """B_cluster of SURVEY §8d from the sequential-rule counters (b = 5 bits per residue, the
+    packed layout the alignment kernel reads)."""
     b = bits
     return ((b * st['sum_len_queries'] + 7) // 8 + 4 * st['posting_visits'] + (b * st['aligned_rep_len'] + 7) // 8
             + (b * st['sum_len_reps'] + 7) // 8 + 4 * st['rep_words'] + 12 * st['n_clustered'])
@@ -190,7 +190,7 @@ def main():
         dom_ms, dom_n = kern[dom]
         if dom == 'align_kernel':   # = align16_kernel (+ the rare wide pairs): residues of the aligned pairs + records
             dom_name = 'align16_kernel'
-            dom_bytes = st['gpu']['aligned_bytes'] + 40 * st['gpu']['aligned']
+            dom_bytes = (5 * st['gpu']['aligned_bytes'] + 7) // 8 + 40 * st['gpu']['aligned']
         elif dom == 'pan_core_sweep_kernel':
             dom_name, dom_bytes = dom, pc_bytes
         else:   # short-word filter passes: (u32 code + u16 mult) per streamed word, two u32 CSR offsets per
@@ -235,7 +235,7 @@ def main():
             'metric': 'proteins/sec clustered at 0.8 identity + pan/core iters/sec, 400-genome set',
             'value': world * n_nr * steps / t_cluster, 'unit': 'proteins/s', 'n_gpus': world, 'steps': steps,
             'warmup': args.warmup, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'u8/i32', 'data': 'synthetic',
             'config': {'workload': '%s: %d genomes x %d CDS synthetic (SURVEY 8d), %d raw records -> %d '
                                    'non-redundant proteins, %d clusters at -c 0.8 -n 5; pan/core %d iterations '
                                    'on synthetic %d x %d matrix' % (args.workload, pset.n_genomes, pset.cds, n_raw,

@@ -100,6 +100,11 @@ struct DevSeqs {
     // Nucleotide clustering with both strands stores the reverse complement of sequence k as
     // the virtual sequence n_fwd + k (same length, own residues and word list): comparing the
     // reverse strand of a query is then an ordinary comparison of that virtual sequence.
+    // 5-bit packed copy of the residues, six per 32-bit word (bits 5t..5t+4 = residue t); sequence k
+    // starts at word pk_off[k]. The alignment kernel stages its operands from this copy with
+    // coalesced word loads and unpacks them into LDS.
+    const uint32_t *pk;
+    const uint32_t *pk_off;
     uint32_t n_fwd;         // number of real sequences
     int32_t base;           // word / k-mer radix: 21 (protein) or 4 (nucleotide)
     int32_t kd;             // k-mer length of the diagonal test: 2 or 4
@@ -176,6 +181,25 @@ __global__ __launch_bounds__(256) void revcomp_kernel(uint8_t *__restrict__ res,
     for (uint32_t i = lane; i < L; i += 64) {
         const uint8_t b = res[src + L - 1 - i];
         res[dst + i] = b < 4 ? (uint8_t)(3 - b) : b;
+    }
+}
+
+// 5-bit packing of every (real and virtual) sequence: one wave per sequence, one word per lane
+__global__ __launch_bounds__(256) void pack5_kernel(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
+                                                   const uint32_t *__restrict__ len,
+                                                   const uint32_t *__restrict__ pk_off, uint32_t n,
+                                                   uint32_t *__restrict__ pk) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const uint8_t *s = res + off[k];
+    const uint32_t L = len[k], nw = (L + 5u) / 6u;
+    uint32_t *dst = pk + pk_off[k];
+    for (uint32_t w = lane; w < nw; w += 64) {
+        uint32_t x = 0;
+        for (uint32_t t = 0; t < 6; ++t)
+            if (6 * w + t < L) x |= (uint32_t)s[6 * w + t] << (5u * t);
+        dst[w] = x;
     }
 }
 
@@ -750,7 +774,7 @@ __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__
 //     forced values, so interior cells never special-case their neighbours.
 // ----------------------------------------------------------------------------------------
 constexpr int kA16Slot = 4096;     // LDS bytes per pair
-constexpr int kA16MaxSum = 4000;   // len1 + len2 handled by the fast path
+constexpr int kA16MaxSum = 4000;   // len1 + len2 handled by the fast path (both, 6-padded, fit the slot)
 constexpr int kScaleShift = 14;
 
 __device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
@@ -796,17 +820,21 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
                    !pair_is_wide(len1, len2, pr.band_left, pr.band_right);
         }
         const int bl = pr.band_left, bw = fast ? pr.band_right - pr.band_left + 1 : 0;
-        // ---- stage both sequences (aligned dword copies keep the source misalignment) ----
+        // ---- stage both sequences: coalesced loads of the 5-bit packed words, unpacked into LDS bytes ----
         int o1 = 0, o2 = 0;
         if (fast) {
-            const uint8_t *g1 = S.res + S.off[k1], *g2 = S.res + S.off[k2];
-            const int a1 = (int)((uintptr_t)g1 & 3u), a2 = (int)((uintptr_t)g2 & 3u);
-            const int w1 = (len1 + a1 + 3) >> 2, w2 = (len2 + a2 + 3) >> 2;
-            const uint32_t *q1 = reinterpret_cast<const uint32_t *>(g1 - a1);
-            const uint32_t *q2 = reinterpret_cast<const uint32_t *>(g2 - a2);
-            for (int w = gl; w < w1; w += 16) seqbuf[slot][w] = q1[w];
-            for (int w = gl; w < w2; w += 16) seqbuf[slot][w1 + w] = q2[w];
-            o1 = a1; o2 = 4 * w1 + a2;
+            const uint32_t *p1 = S.pk + S.pk_off[k1], *p2 = S.pk + S.pk_off[k2];
+            const int w1 = (len1 + 5) / 6, w2 = (len2 + 5) / 6;
+            uint8_t *sbw = reinterpret_cast<uint8_t *>(seqbuf[slot]);
+            o2 = (6 * w1 + 7) & ~7;
+            for (int w = gl; w < w1; w += 16) {
+                const uint32_t x = p1[w];
+                for (int t = 0; t < 6; ++t) sbw[6 * w + t] = (uint8_t)((x >> (5 * t)) & 31u);
+            }
+            for (int w = gl; w < w2; w += 16) {
+                const uint32_t x = p2[w];
+                for (int t = 0; t < 6; ++t) sbw[o2 + 6 * w + t] = (uint8_t)((x >> (5 * t)) & 31u);
+            }
         }
         // ---- per-lane geometry of its two band columns -------------------------------------
         const int c0 = 2 * gl, c1 = c0 + 1;
@@ -1083,6 +1111,13 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     h_off[0] = 0;
     for (uint32_t k = 0; k < nv; ++k) { h_len[k] = in_len[order[k < n ? k : k - n]]; h_off[k + 1] = h_off[k] + h_len[k]; }
     const uint64_t total = h_off[nv];
+    std::vector<uint32_t> h_pkoff((size_t)nv + 1);
+    h_pkoff[0] = 0;
+    for (uint32_t k = 0; k < nv; ++k) {
+        const uint64_t nxt = (uint64_t)h_pkoff[k] + (h_len[k] + 5) / 6;
+        if (nxt > 0xFFFFFFF0ull) { pgx_set_error("pgx_cluster_greedy: too many residues for 32-bit packed offsets"); return PGX_ERR_CAPACITY; }
+        h_pkoff[k + 1] = (uint32_t)nxt;
+    }
     // per-query thresholds in double, exactly as the sequential rule computes them
     std::vector<int32_t> h_aa1(n), h_aas(n), h_aan(n);
     for (uint32_t k = 0; k < n; ++k) {
@@ -1119,12 +1154,12 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
         d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather, d_bi_cnt2, d_bi_off2, d_bi_fill2, d_bi_ent2,
-        d_pairsA2, d_scan_tmp2, d_nA2;
+        d_pairsA2, d_scan_tmp2, d_nA2, d_pk, d_pkoff;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
                          &d_bi_cnt, &d_bi_off, &d_bi_fill, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
                          &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_list, &d_gather,
-                         &d_bi_cnt2, &d_bi_off2, &d_bi_fill2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2};
+                         &d_bi_cnt2, &d_bi_off2, &d_bi_fill2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2, &d_pk, &d_pkoff};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -1134,6 +1169,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_wcode.alloc((total + 16) * 4));
     PGX_HIP(d_wmult.alloc((total + 16) * 2));
     PGX_HIP(d_wcnt.alloc((size_t)nv * 4));
+    PGX_HIP(d_pk.alloc(((size_t)h_pkoff[nv] + 16) * 4));
+    PGX_HIP(d_pkoff.alloc(((size_t)nv + 1) * 4));
+    PGX_HIP(hipMemcpyAsync(d_pkoff.p, h_pkoff.data(), ((size_t)nv + 1) * 4, hipMemcpyHostToDevice, st));
     PGX_HIP(d_aa1.alloc((size_t)n * 4));
     PGX_HIP(d_aas.alloc((size_t)n * 4));
     PGX_HIP(d_aan.alloc((size_t)n * 4));
@@ -1189,6 +1227,8 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         if (both)
             revcomp_kernel<<<(n + 3) / 4, 256, 0, st>>>(d_res.as<uint8_t>(), d_off.as<uint64_t>(),
                                                         d_len.as<uint32_t>(), n);
+        pack5_kernel<<<(nv + 3) / 4, 256, 0, st>>>(d_res.as<uint8_t>(), d_off.as<uint64_t>(), d_len.as<uint32_t>(),
+                                                   d_pkoff.as<uint32_t>(), nv, d_pk.as<uint32_t>());
     }
     LAUNCH_CHECK();
     PGX_HIP(hipMemcpyAsync(d_aa1.p, h_aa1.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1220,7 +1260,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     }
     DevSeqs DS{d_res.as<uint8_t>(), d_off.as<uint64_t>(), d_len.as<uint32_t>(),
                d_wcode.as<uint32_t>(), d_wmult.as<uint16_t>(), d_wcnt.as<uint32_t>(),
-               n, nt ? 4 : kNAA1, nt ? 4 : 2, nt ? 1 : 0};
+               d_pk.as<uint32_t>(), d_pkoff.as<uint32_t>(), n, nt ? 4 : kNAA1, nt ? 4 : 2, nt ? 1 : 0};
     std::vector<uint32_t> h_wcnt(n);
     PGX_HIP(hipMemcpyAsync(h_wcnt.data(), d_wcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 
