@@ -235,7 +235,7 @@ def main():
             'metric': 'proteins/sec clustered at 0.8 identity + pan/core iters/sec, 400-genome set',
             'value': world * n_nr * steps / t_cluster, 'unit': 'proteins/s', 'n_gpus': world, 'steps': steps,
             'warmup': args.warmup, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'u8/i32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'i32', 'data': 'synthetic',
             'config': {'workload': '%s: %d genomes x %d CDS synthetic (SURVEY 8d), %d raw records -> %d '
                                    'non-redundant proteins, %d clusters at -c 0.8 -n 5; pan/core %d iterations '
                                    'on synthetic %d x %d matrix' % (args.workload, pset.n_genomes, pset.cds, n_raw,
