@@ -157,6 +157,8 @@ def main():
     if args.only != 'all':
         if rank == 0:
             log('--only %s: %d step(s) done in %.3f s (no JSON line)' % (args.only, args.steps, dt))
+            for k_, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0]):
+                log('  %-24s %9.3f ms %6d launches' % (k_, v[0], v[1]))
         ctx.close()
         return
     if rank == 0:

@@ -312,19 +312,20 @@ __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t 
 //               key can still beat the query's current best.
 //   MODE_BLOCK  table = the current block of still-unassigned members; only later members of
 //               the same block are compared (the block is then resolved in order on the host).
-//   MODE_FLAG   table = every still-unassigned member of the sweep; nothing is emitted, only
-//               flag_out[q] = 1 for unassigned members that have an earlier candidate among
-//               them. A member without one is certainly a new representative.
-enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2, MODE_FLAG = 3 };
+// TABLE streams tens of thousands of representatives on the side stream (256 threads, many
+// workgroups per CU); NEW and BLOCK have a few hundred table entries and are bound by the
+// latency of one workgroup's walk, so they run 1024 threads wide (kCountWide).
+enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2 };
 constexpr unsigned long long kNoBest = ~0ull;
 constexpr uint32_t kNewBit = 0x80000000u;
 constexpr uint32_t kLongMin = 16, kLongCap = 512;  // posting lists walked wave-cooperatively
+constexpr int kCountWide = 1024;
 
 // NT adds per-query visit counters for the reverse-strand slots: the one-by-one pass only walks
 // a query's reverse-complement words when its forward strand found no representative, so
 // those visits are attributed per query (rc_visits) and summed on the host for such queries.
-template <int MODE, bool NT>
-__global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *__restrict__ table,
+template <int MODE, bool NT, int THREADS>
+__global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_t *__restrict__ table,
                                                    const uint32_t *__restrict__ d_ntable,
                                                    uint32_t ntable_host, uint32_t b0, uint32_t nb, uint32_t nbq,
                                                    const uint32_t *__restrict__ bi_off,
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
                                                    uint32_t pair_cap,
                                                    unsigned long long *__restrict__ visits,
                                                    unsigned long long *__restrict__ rc_visits,
-                                                   uint8_t *__restrict__ flag_out, uint32_t rep_base) {
+                                                   uint32_t rep_base) {
     __shared__ uint32_t cnt[kBatchCap];
     __shared__ uint32_t minc[kBatchCap];
     __shared__ uint32_t vis[NT ? kBatchCap : 1];
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
     __shared__ unsigned long long wg_visits;
     const uint32_t ntable = d_ntable ? *d_ntable : ntable_host;
     for (uint32_t r = blockIdx.x; r < ntable; r += gridDim.x) {
-        for (uint32_t q = threadIdx.x; q < nb; q += 256) { cnt[q] = 0u; minc[q] = kSentinel; if (NT) vis[q] = 0u; }
+        for (uint32_t q = threadIdx.x; q < nb; q += THREADS) { cnt[q] = 0u; minc[q] = kSentinel; if (NT) vis[q] = 0u; }
         if (threadIdx.x == 0) { wg_visits = 0ull; n_long = 0u; }
         __syncthreads();
         const uint32_t k = table[r];
@@ -358,13 +359,12 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
             const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
             if (MODE != MODE_TABLE && b0 + (q >= nbq ? q - nbq : q) <= k) return;  // only queries after the representative
             atomicAdd(&cnt[q], m < mq ? m : mq);
-            if (MODE == MODE_FLAG) return;  // only "has a candidate" is wanted: no key
             atomicMin(&minc[q], code);
             if (MODE == MODE_BLOCK) return;  // visits are counted by the TABLE / NEW passes
             if (NT && q >= nbq) atomicAdd(&vis[q], 1u);  // reverse strand: attributed to the query
             else ++my_visits;
         };
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
             const uint32_t code = S.wcode[o + i];
             const uint32_t m = S.wmult[o + i];
             const uint32_t lo = bi_off[code], hi = bi_off[code + 1];
@@ -378,23 +378,26 @@ __global__ __launch_bounds__(256) void count_kernel(DevSeqs S, const uint32_t *_
         {
             const uint32_t nl = n_long < kLongCap ? n_long : kLongCap;
             const uint32_t lane = threadIdx.x & 63u;
-            for (uint32_t w = threadIdx.x >> 6; w < nl; w += 4) {
+            for (uint32_t w = threadIdx.x >> 6; w < nl; w += THREADS / 64) {
                 const uint32_t lo = lq_lo[w], len = lq_meta[w] >> 16, m = lq_meta[w] & 0xFFFFu, code = lq_code[w];
-                for (uint32_t e = lane; e < len; e += 64) visit(bi_ent[lo + e], m, code);
+                // four coalesced loads in flight per wave: the walk is bound by their latency
+                for (uint32_t e = lane; e < len; e += 256) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = e + 64u * t < len ? bi_ent[lo + e + 64u * t] : 0u;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (e + 64u * t < len) visit(v[t], m, code);
+                }
             }
         }
         if (my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
         __syncthreads();
-        for (uint32_t q = threadIdx.x; q < nb; q += 256) {
+        for (uint32_t q = threadIdx.x; q < nb; q += THREADS) {
             const uint32_t c = cnt[q];
             const uint32_t ql = q >= nbq ? q - nbq : q;  // the query's local index; q >= nbq = reverse strand
             if (NT && (MODE == MODE_TABLE || MODE == MODE_NEW) && q >= nbq && vis[q])
                 atomicAdd(&rc_visits[ql], (unsigned long long)vis[q]);
             if (c == 0u || (int32_t)c < req_aan[b0 + ql]) continue;
-            if (MODE == MODE_FLAG) {
-                if (qflag[ql]) flag_out[ql] = 1;  // an unassigned member with an earlier unassigned candidate
-                continue;
-            }
             if (MODE == MODE_NEW) {
                 if (qflag[ql]) continue;  // resolved inside a block already
                 const unsigned long long bo = best[ql];
@@ -464,16 +467,56 @@ __global__ __launch_bounds__(256) void list_open_kernel(const unsigned long long
     is_open[q] = open;
     if (open) ulist[atomicAdd(n_open, 1u)] = b0 + q;
 }
-// Unassigned members without an earlier unassigned candidate are new representatives for
-// certain: list them (any order; they are numbered by sequence order later) and retire them.
-__global__ __launch_bounds__(256) void select_certain_kernel(const uint8_t *__restrict__ is_open,
-                                                            const uint8_t *__restrict__ has_cand,
-                                                            uint8_t *__restrict__ done, uint32_t b0, uint32_t nb,
-                                                            uint32_t *__restrict__ list, uint32_t *__restrict__ n_list) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nb || !is_open[q] || has_cand[q]) return;
-    done[q] = 1;
-    list[atomicAdd(n_list, 1u)] = b0 + q;
+// Discovery of certain representatives in time linear in the sweep's words. first[code] holds,
+// tagged with the sweep's epoch, the earliest still-unassigned member whose word list has
+// `code` (stored as epoch << 12 | 4095 - member so that a plain atomicMax keeps the earliest
+// member of the newest epoch; no per-sweep reset).
+static_assert(kBatchCap <= 4096, "first-open tags keep the member in 12 bits");
+__global__ __launch_bounds__(256) void first_open_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
+                                                        const uint32_t *__restrict__ n_open, uint32_t b0,
+                                                        uint32_t epoch, uint32_t *__restrict__ first) {
+    const uint32_t lane = threadIdx.x & 63u, n = *n_open;
+    for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
+        const uint32_t k = ulist[w];
+        const uint64_t o = S.off[k];
+        const uint32_t nw = S.wcnt[k], tag = (epoch << 12) | (4095u - (k - b0));
+        for (uint32_t i = lane; i < nw; i += 64) atomicMax(&first[S.wcode[o + i]], tag);
+    }
+}
+// A member can only have an earlier unassigned candidate r if it shares at least its word
+// threshold with r, and the words it shares with r are among its words that ANY earlier
+// unassigned member has. When even that count stays below the threshold (on both strands) the
+// member is a new representative for certain: listed (any order; they are numbered by sequence
+// order later) and retired. Typically that is the first member of every family that appears in
+// this sweep. One wave per member.
+__global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
+                                                     const uint32_t *__restrict__ n_open, uint32_t b0,
+                                                     uint32_t both, uint32_t epoch,
+                                                     const uint32_t *__restrict__ first,
+                                                     const int32_t *__restrict__ req_aan,
+                                                     uint8_t *__restrict__ done, uint32_t *__restrict__ list,
+                                                     uint32_t *__restrict__ n_list) {
+    const uint32_t lane = threadIdx.x & 63u, n = *n_open;
+    for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
+        const uint32_t k = ulist[w], ql = k - b0;
+        bool cand = false;
+        for (uint32_t strand = 0; strand < (both ? 2u : 1u) && !cand; ++strand) {
+            const uint32_t ks = strand ? S.n_fwd + k : k;
+            const uint64_t o = S.off[ks];
+            const uint32_t nw = S.wcnt[ks];
+            uint32_t sum = 0;
+            for (uint32_t i = lane; i < nw; i += 64) {
+                const uint32_t f = first[S.wcode[o + i]];
+                if ((f >> 12) == epoch && 4095u - (f & 4095u) < ql) sum += S.wmult[o + i];
+            }
+            for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+            cand = sum != 0u && (int32_t)sum >= req_aan[k];
+        }
+        if (!cand && lane == 0) {
+            done[ql] = 1;
+            list[atomicAdd(n_list, 1u)] = k;
+        }
+    }
 }
 
 // block members are final once the host has walked the block
@@ -791,6 +834,8 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
                                                      uint32_t key_flag) {
     __shared__ int32_t tab[4][kNAA1 * kNAA1];
     __shared__ uint32_t seqbuf[16][kA16Slot / 4];
+    // one wave per SIMD, bound by its own dependent chain: issue ahead of the side stream's table pass
+    __builtin_amdgcn_s_setprio(3);
     for (int c = threadIdx.x; c < 4 * kNAA1 * kNAA1; c += 256) {
         const int cc = c % (kNAA1 * kNAA1);
         const int s = S.nt ? (cc / kNAA1 == cc % kNAA1 ? 2 : -2) : (int)kBlosum62_dev[cc];
@@ -1154,12 +1199,12 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
         d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather, d_bi_cnt2, d_bi_off2, d_bi_fill2, d_bi_ent2,
-        d_pairsA2, d_scan_tmp2, d_nA2, d_pk, d_pkoff;
+        d_pairsA2, d_scan_tmp2, d_nA2, d_pk, d_pkoff, d_first;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
                          &d_bi_cnt, &d_bi_off, &d_bi_fill, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
                          &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_list, &d_gather,
-                         &d_bi_cnt2, &d_bi_off2, &d_bi_fill2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2, &d_pk, &d_pkoff};
+                         &d_bi_cnt2, &d_bi_off2, &d_bi_fill2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2, &d_pk, &d_pkoff, &d_first};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -1179,6 +1224,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_bi_cnt.alloc(((size_t)n_codes + 1) * 4));
     PGX_HIP(d_bi_off.alloc(((size_t)n_codes + 1) * 4));
     PGX_HIP(d_bi_fill.alloc((size_t)n_codes * 4));
+    PGX_HIP(d_first.alloc((size_t)n_codes * 4));
     PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
     PGX_HIP(d_best_old.alloc(kBatchCap * 16));  // best keys + reverse-strand visit counters
     PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
@@ -1374,12 +1420,12 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             LAUNCH_CHECK();
             if (n_table) {
                 ProfScope prof(ctx, "count_kernel<table>", hs);
-                auto kern = nt ? count_kernel<MODE_TABLE, true> : count_kernel<MODE_TABLE, false>;
+                auto kern = nt ? count_kernel<MODE_TABLE, true, 256> : count_kernel<MODE_TABLE, false, 256>;
                 // on the side stream leave room (LDS, wave slots) for the main stream's small kernels
                 kern<<<std::min(n_table, hs == st ? 4096u : 512u), 256, 0, hs>>>(
                     DS, d_rep_seq.as<uint32_t>(), nullptr, n_table, hb0, hns, hnb, W.bi_off, W.bi_ent,
                     d_aan.as<int32_t>(), nullptr, nullptr, W.pairsA, W.nA, pair_cap,
-                    d_visits.as<unsigned long long>(), d_rcvis, nullptr, 0u);
+                    d_visits.as<unsigned long long>(), d_rcvis, 0u);
                 LAUNCH_CHECK();
             }
             return PGX_OK;
@@ -1399,11 +1445,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         }
         if (n_reps > n_pre) {  // representatives created after the head was enqueued (the previous sweep's)
             ProfScope prof(ctx, "count_kernel<table>", st);
-            auto kern = nt ? count_kernel<MODE_TABLE, true> : count_kernel<MODE_TABLE, false>;
+            auto kern = nt ? count_kernel<MODE_TABLE, true, 256> : count_kernel<MODE_TABLE, false, 256>;
             kern<<<std::min(n_reps - n_pre, 4096u), 256, 0, st>>>(
                 DS, d_rep_seq.as<uint32_t>() + n_pre, nullptr, n_reps - n_pre, b0, ns, nb, B.bi_off, B.bi_ent,
                 d_aan.as<int32_t>(), nullptr, nullptr, B.pairsA, B.nA, pair_cap, d_visits.as<unsigned long long>(),
-                d_rcvis, nullptr, n_pre);
+                d_rcvis, n_pre);
             LAUNCH_CHECK();
         }
         // diag + align of a selection of pair records, enqueued on the stream
@@ -1454,37 +1500,34 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             snapshot_kernel<<<1, 1, 0, st>>>(d_nN, d_nN0);
             {
                 ProfScope prof(ctx, "count_kernel<new>", st);
-                auto kern = nt ? count_kernel<MODE_NEW, true> : count_kernel<MODE_NEW, false>;
-                kern<<<nr, 256, 0, st>>>(DS, d_new, nullptr, nr, b0, ns, nb, B.bi_off,
+                auto kern = nt ? count_kernel<MODE_NEW, true, kCountWide> : count_kernel<MODE_NEW, false, kCountWide>;
+                kern<<<nr, kCountWide, 0, st>>>(DS, d_new, nullptr, nr, b0, ns, nb, B.bi_off,
                                          B.bi_ent, d_aan.as<int32_t>(), d_best, d_done,
                                          d_pairsN.as<Pair>(), d_nN, pair_cap, d_visits.as<unsigned long long>(),
-                                         d_rcvis, nullptr, 0u);
+                                         d_rcvis, 0u);
             }
             LAUNCH_CHECK();
             const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, b0, 0};
             return evaluate(nullptr, d_pairsN.as<Pair>(), selN, d_best, kNewBit, 0);
         };
-        // Discovery: among all still-unassigned members, those without an earlier unassigned
-        // candidate are certain new representatives (typically the first member of every family
-        // that appears in this sweep). They are confirmed in one step, and the pass against
-        // them assigns most of the remaining members before any block is formed.
+        // Discovery: still-unassigned members that cannot have an earlier unassigned candidate are
+        // certain new representatives (first_open_kernel / certain_kernel). They are confirmed in
+        // one step, and the pass against them assigns most of the remaining members before any
+        // block is formed.
         {
-            PGX_HIP(hipMemsetAsync(d_blk, 0, 8, st));            // counters [4] open, [5] certain
-            PGX_HIP(hipMemsetAsync(d_hascand, 0, kBatchCap, st));
             list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_blk_list.as<uint32_t>(),
-                                                               d_skip2, d_blk);
+                                                               d_skip2, d_blk);  // d_blk[0] open, [1] certain: zero since the sweep began
             LAUNCH_CHECK();
+            const uint32_t epoch = 1u + (uint32_t)((S.sweeps - 1) % 0xFFFFFu);
+            if (epoch == 1u) PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)n_codes * 4, st));
             {
-                ProfScope prof(ctx, "count_kernel<flag>", st);
-                auto kern = nt ? count_kernel<MODE_FLAG, true> : count_kernel<MODE_FLAG, false>;
-                kern<<<std::min(nb, 4096u), 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb,
-                                                          B.bi_off, B.bi_ent,
-                                                          d_aan.as<int32_t>(), nullptr, d_skip2, nullptr, nullptr, 0,
-                                                          nullptr, d_rcvis, d_hascand, 0u);
+                ProfScope prof(ctx, "discover_kernels", st);
+                first_open_kernel<<<(nb + 3) / 4, 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), d_blk, b0, epoch,
+                                                                d_first.as<uint32_t>());
+                certain_kernel<<<(nb + 3) / 4, 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), d_blk, b0, both ? 1u : 0u,
+                                                             epoch, d_first.as<uint32_t>(), d_aan.as<int32_t>(), d_done,
+                                                             d_new_list.as<uint32_t>(), d_blk + 1);
             }
-            LAUNCH_CHECK();
-            select_certain_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_skip2, d_hascand, d_done, b0, nb,
-                                                                    d_new_list.as<uint32_t>(), d_blk + 1);
             LAUNCH_CHECK();
             PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
             PGX_HIP(hipMemcpyAsync(h_new.p, d_new_list.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
@@ -1504,10 +1547,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             PGX_HIP(hipMemsetAsync(d_nK, 0, 4, st));
             {
                 ProfScope prof(ctx, "count_kernel<block>", st);
-                auto kern = nt ? count_kernel<MODE_BLOCK, true> : count_kernel<MODE_BLOCK, false>;
-                kern<<<kBlockCap, 256, 0, st>>>(
+                auto kern = nt ? count_kernel<MODE_BLOCK, true, kCountWide> : count_kernel<MODE_BLOCK, false, kCountWide>;
+                kern<<<kBlockCap, kCountWide, 0, st>>>(
                     DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, B.bi_off, B.bi_ent,
-                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis, nullptr, 0u);
+                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis, 0u);
             }
             LAUNCH_CHECK();
             // A block member without an earlier in-block candidate is certainly a new

@@ -25,7 +25,7 @@ WIDE_READ = {'pan_core_sweep_kernel'}          # 16 B / lane streaming reads
 def short(name):
     name = name.replace('(anonymous namespace)::', '')
     name = name.split('(')[0].replace('void ', '').strip()
-    m = re.match(r'count_kernel<(\d)(, (true|false))?>', name)
+    m = re.match(r'count_kernel<(\d)(, (true|false))?(, \d+)?>', name)
     if m:
         return 'count_kernel<%s>' % ('table', 'new', 'block', 'flag')[int(m.group(1))]
     return name
