@@ -68,14 +68,16 @@ struct Pair {           // one (query, representative) candidate
 };
 
 // Which pair records a diag / align launch works on: the device-side range
-// [*d_begin, min(*d_end, cap)) or an explicit list; optionally skipping pairs whose
-// candidate (a batch member, local index r - b0) has `skip_flag` set.
+// [*d_begin, min(*d_end, cap)) or an explicit list; optionally only pairs whose candidate (a
+// batch member, local index r - b0) has `only_a` set and/or `only_not_b` clear. Accepted
+// pairs can be reported per query in `accepted_out` (local index).
 struct PairSel {
     const uint32_t *d_begin, *d_end;
     uint32_t cap;
     const uint32_t *list;
     uint32_t n_list;
-    const uint8_t *skip_flag;
+    const uint8_t *only_a, *only_not_b;
+    uint8_t *accepted_out;
     uint32_t b0;
     uint32_t skip_evaluated;  // leave pairs alone that an earlier round has been through
 };
@@ -284,9 +286,11 @@ __global__ __launch_bounds__(256) void index_hist_kernel(DevSeqs S, uint32_t b0,
     for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&bi_cnt[S.wcode[o + i]], 1u);
 }
 
+// Slots of a list are handed out by counting bi_cnt back down, which leaves the 16 MB count
+// table all zero again for the next sweep that uses it (no per-sweep clear).
 __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t b0, uint32_t nb, uint32_t nbq,
                                                            const uint32_t *__restrict__ bi_off,
-                                                           uint32_t *__restrict__ bi_fill,
+                                                           uint32_t *__restrict__ bi_cnt,
                                                            uint32_t *__restrict__ bi_ent) {
     if (blockIdx.x >= nb) return;
     const uint32_t k = slot_seq(S, b0, nbq, blockIdx.x);
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t 
     const uint32_t n = S.wcnt[k];
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
         const uint32_t code = S.wcode[o + i];
-        const uint32_t pos = bi_off[code] + atomicAdd(&bi_fill[code], 1u);
+        const uint32_t pos = bi_off[code] + atomicSub(&bi_cnt[code], 1u) - 1u;
         bi_ent[pos] = (blockIdx.x << 16) | S.wmult[o + i];
     }
 }
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
                                                    uint32_t pair_cap,
                                                    unsigned long long *__restrict__ visits,
                                                    unsigned long long *__restrict__ rc_visits,
-                                                   uint32_t rep_base) {
+                                                   uint8_t *__restrict__ mark_out, uint32_t rep_base) {
     __shared__ uint32_t cnt[kBatchCap];
     __shared__ uint32_t minc[kBatchCap];
     __shared__ uint32_t vis[NT ? kBatchCap : 1];
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
                 if (bo != kNoBest && hi >= (bo & 0xFFFFFFFF00000000ull)) continue;
             }
             if (MODE == MODE_BLOCK && !qflag[ql]) continue;  // not in the current block
+            if (MODE == MODE_BLOCK) mark_out[ql] = 1;        // this block member has an earlier in-block candidate
             const uint32_t slot = atomicAdd(n_pairs, 1u);
             if (slot < pair_cap) {
                 Pair p;
@@ -427,8 +432,13 @@ __global__ __launch_bounds__(1024) void select_block_kernel(const unsigned long 
                                                            uint8_t *__restrict__ inblk, uint32_t b0,
                                                            uint32_t nb, uint32_t block_cap,
                                                            uint32_t *__restrict__ blk_list,
-                                                           uint32_t *__restrict__ counters) {
+                                                           uint32_t *__restrict__ counters,
+                                                           uint32_t *__restrict__ n_k,
+                                                           unsigned long long *__restrict__ zero8k) {
     __shared__ uint32_t part[1024];
+    static_assert(2 * kBatchCap == 1024 * 8, "has_cand + accepted are cleared by this kernel, 8 bytes per thread");
+    zero8k[threadIdx.x] = 0ull;
+    if (threadIdx.x == 0) *n_k = 0u;
     constexpr int PER = kBatchCap / 1024;
     const uint32_t tid = threadIdx.x;
     bool cand[PER];
@@ -495,8 +505,11 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
                                                      const uint32_t *__restrict__ first,
                                                      const int32_t *__restrict__ req_aan,
                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ list,
-                                                     uint32_t *__restrict__ n_list) {
+                                                     uint32_t *__restrict__ n_list,
+                                                     const uint32_t *__restrict__ snap_src,
+                                                     uint32_t *__restrict__ snap_dst) {
     const uint32_t lane = threadIdx.x & 63u, n = *n_open;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *snap_dst = *snap_src;  // where the next pass's pair records begin
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
         const uint32_t k = ulist[w], ql = k - b0;
         bool cand = false;
@@ -520,40 +533,42 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
 }
 
 // block members are final once the host has walked the block
-__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb) {
+__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb,
+                                    const uint32_t *__restrict__ snap_src, uint32_t *__restrict__ snap_dst) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0) *snap_dst = *snap_src;  // where the next pass's pair records begin
     if (q < nb && inblk[q]) { done[q] = 1; inblk[q] = 0; }
 }
 
-// has_cand[q - b0] = 1 for every block member that has an earlier in-block candidate; a member
-// without one (and without a representative so far) is certainly a new representative
-__global__ __launch_bounds__(256) void mark_candidates_kernel(const Pair *__restrict__ pairs,
-                                                             const uint32_t *__restrict__ d_n, uint32_t cap,
-                                                             uint32_t b0, uint32_t n_fwd,
-                                                             uint8_t *__restrict__ has_cand) {
-    uint32_t n = *d_n;
-    if (n > cap) n = cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        has_cand[(pairs[i].q >= n_fwd ? pairs[i].q - n_fwd : pairs[i].q) - b0] = 1;
+// Start of a sweep: counters, best keys, reverse-strand visit counters and member flags in one launch.
+__global__ __launch_bounds__(256) void sweep_init_kernel(uint32_t *__restrict__ counters,
+                                                        unsigned long long *__restrict__ best,
+                                                        unsigned long long *__restrict__ rc_visits,
+                                                        uint8_t *__restrict__ done_inblk) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // grid covers kBatchCap
+    if (q < 8) counters[q] = 0u;
+    best[q] = kNoBest;
+    if (rc_visits) rc_visits[q] = 0ull;
+    if (q < 2 * kBatchCap / 8) reinterpret_cast<unsigned long long *>(done_inblk)[q] = 0ull;
 }
 
-// After the first in-block round: a member that has candidates but was accepted by none of
-// the certain representatives is LIKELY a representative itself (an outlier of its family).
-// skip2[u] = 0 exactly for those, so the second round evaluates the pairs against them.
-__global__ __launch_bounds__(256) void mark_accepted_kernel(const Pair *__restrict__ pairs,
-                                                           const uint32_t *__restrict__ d_n, uint32_t cap,
-                                                           uint32_t b0, uint32_t n_fwd,
-                                                           uint8_t *__restrict__ accepted) {
-    uint32_t n = *d_n;
-    if (n > cap) n = cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        if (pairs[i].flags & F_ACCEPT) accepted[(pairs[i].q >= n_fwd ? pairs[i].q - n_fwd : pairs[i].q) - b0] = 1;
-}
-__global__ __launch_bounds__(256) void likely_rep_kernel(const uint8_t *__restrict__ has_cand,
-                                                        const uint8_t *__restrict__ accepted, uint32_t nb,
-                                                        uint8_t *__restrict__ skip2) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nb) skip2[q] = !(has_cand[q] && !accepted[q]);
+// One round trip's worth of results written straight into page-locked host memory: each
+// segment copies min(*count or `fixed`, cap) records of `words` dwords. Replaces a string of
+// small device-to-host copies (each one a blit launch of its own) by a single launch, and
+// copies exactly the records that exist.
+constexpr uint32_t kPairWords = sizeof(Pair) / 4;
+static_assert(sizeof(Pair) % 4 == 0, "pair records are published as dwords");
+struct PubSeg { const uint32_t *src; uint32_t *dst; const uint32_t *count; uint32_t fixed, words, cap; };
+constexpr int kPubSegs = 6;
+struct PubArgs { PubSeg seg[kPubSegs]; int n; };
+__global__ __launch_bounds__(256) void publish_kernel(PubArgs a) {
+    for (int s = 0; s < a.n; ++s) {
+        const PubSeg g = a.seg[s];
+        uint32_t c = g.count ? *g.count : g.fixed;
+        if (c > g.cap) c = g.cap;
+        const uint32_t total = c * g.words;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) g.dst[i] = g.src[i];
+    }
 }
 
 __global__ __launch_bounds__(256) void gather_pairs_kernel(const Pair *__restrict__ pairs,
@@ -563,7 +578,6 @@ __global__ __launch_bounds__(256) void gather_pairs_kernel(const Pair *__restric
     if (i < n) out[i] = pairs[list[i]];
 }
 
-__global__ void snapshot_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) { *dst = *src; }
 
 // ----------------------------------------------------------------------------------------
 // diag: 2-mer diagonal histogram + best band (one wave per pair)
@@ -653,7 +667,8 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
     for (uint32_t w = blockIdx.x; w < np; w += gridDim.x) {
         const uint32_t p = sel_pair(sel, w);
         const Pair pr = pairs[p];
-        if (sel.skip_flag && sel.skip_flag[pr.r - sel.b0]) continue;  // block-uniform
+        if (sel.only_a && !sel.only_a[pr.r - sel.b0]) continue;  // block-uniform
+        if (sel.only_not_b && sel.only_not_b[pr.r - sel.b0]) continue;
         if (sel.skip_evaluated && (pr.flags & F_EVAL)) continue;
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
         const uint32_t k1r = real_of(S, k1);  // thresholds are the query's, whichever strand
@@ -977,6 +992,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
             }
             pairs[p].iden = iden;
             pairs[p].flags = pr.flags | F_ALIGNED | (ok ? F_ACCEPT : 0u);
+            if (ok && sel.accepted_out) sel.accepted_out[k1r - b0] = 1;
             if (ok && best)
                 atomicMin(&best[k1r - b0], ((unsigned long long)(k1 != k1r) << 63) | ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
         }
@@ -1016,6 +1032,7 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
         if (lane == 0) {
             pairs[p].iden = iden;
             pairs[p].flags = pr.flags | F_ALIGNED | (ok ? F_ACCEPT : 0u);
+            if (ok && sel.accepted_out) sel.accepted_out[k1r - b0] = 1;
             if (ok && best)
                 atomicMin(&best[k1r - b0], ((unsigned long long)(k1 != k1r) << 63) | ((unsigned long long)pr.minc << 32) | key_flag | pr.r);
         }
@@ -1197,14 +1214,14 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     const uint32_t gs_stride = 3u * (kMaxLen + 1);
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
-        d_bi_fill, d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
-        d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather, d_bi_cnt2, d_bi_off2, d_bi_fill2, d_bi_ent2,
+        d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
+        d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather, d_bi_cnt2, d_bi_off2, d_bi_ent2,
         d_pairsA2, d_scan_tmp2, d_nA2, d_pk, d_pkoff, d_first;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
-                         &d_bi_cnt, &d_bi_off, &d_bi_fill, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
+                         &d_bi_cnt, &d_bi_off, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
                          &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_list, &d_gather,
-                         &d_bi_cnt2, &d_bi_off2, &d_bi_fill2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2, &d_pk, &d_pkoff, &d_first};
+                         &d_bi_cnt2, &d_bi_off2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2, &d_pk, &d_pkoff, &d_first};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -1222,8 +1239,8 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_aan.alloc((size_t)n * 4));
     PGX_HIP(d_rep_seq.alloc((size_t)n * 4));
     PGX_HIP(d_bi_cnt.alloc(((size_t)n_codes + 1) * 4));
+    PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));  // once: every sweep leaves it zero again
     PGX_HIP(d_bi_off.alloc(((size_t)n_codes + 1) * 4));
-    PGX_HIP(d_bi_fill.alloc((size_t)n_codes * 4));
     PGX_HIP(d_first.alloc((size_t)n_codes * 4));
     PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
     PGX_HIP(d_best_old.alloc(kBatchCap * 16));  // best keys + reverse-strand visit counters
@@ -1249,17 +1266,17 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_nA2.alloc(64));
     if (pipeline) {
         PGX_HIP(d_bi_cnt2.alloc(((size_t)n_codes + 1) * 4));
+        PGX_HIP(hipMemsetAsync(d_bi_cnt2.p, 0, ((size_t)n_codes + 1) * 4, st));
         PGX_HIP(d_bi_off2.alloc(((size_t)n_codes + 1) * 4));
-        PGX_HIP(d_bi_fill2.alloc((size_t)n_codes * 4));
         PGX_HIP(d_bi_ent2.alloc((max_batch_words + 16) * 4));
         PGX_HIP(d_pairsA2.alloc((size_t)pair_cap * sizeof(Pair)));
         PGX_HIP(d_scan_tmp2.alloc(scan_bytes));
     }
-    struct SweepBuf { uint32_t *bi_cnt, *bi_off, *bi_fill, *bi_ent; Pair *pairsA; uint32_t *nA; void *scan_tmp; };
+    struct SweepBuf { uint32_t *bi_cnt, *bi_off, *bi_ent; Pair *pairsA; uint32_t *nA; void *scan_tmp; };
     SweepBuf sbuf[2] = {
-        {d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(), d_bi_fill.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
+        {d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
          d_pairsA.as<Pair>(), d_nA2.as<uint32_t>(), d_scan_tmp.p},
-        {d_bi_cnt2.as<uint32_t>(), d_bi_off2.as<uint32_t>(), d_bi_fill2.as<uint32_t>(), d_bi_ent2.as<uint32_t>(),
+        {d_bi_cnt2.as<uint32_t>(), d_bi_off2.as<uint32_t>(), d_bi_ent2.as<uint32_t>(),
          d_pairsA2.as<Pair>(), d_nA2.as<uint32_t>() + 8, d_scan_tmp2.p}};
 
     PGX_HIP(d_order.alloc((size_t)n * 4));
@@ -1324,8 +1341,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     constexpr uint32_t kPrefix = 4096;  // pairs copied back together with the counters
     PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(8)); PGX_HIP(h_blk.reserve(kBatchCap));
     PGX_HIP(h_new.reserve(kBatchCap)); PGX_HIP(hK.reserve(pair_cap_k)); PGX_HIP(hA.reserve(kPrefix)); PGX_HIP(hN.reserve(kPrefix));
-    // device counters: [0] pairsA, [1] pairsN, [2] pairsK, [3] pairsN range start, [4] block size, [5] open members
-    uint32_t *d_nN = d_counters.as<uint32_t>() + 1, *d_nK = d_nN + 1, *d_nN0 = d_nN + 2, *d_blk = d_nN + 3;
+    // device counters: [1] pairsN, [2] pairsK, [3] pairsN range start, [4] open members / block size,
+    // [5] open members left, [6] certain representatives of the sweep
+    uint32_t *d_nN = d_counters.as<uint32_t>() + 1, *d_nK = d_nN + 1, *d_nN0 = d_nN + 2, *d_blk = d_nN + 3,
+             *d_ncertain = d_counters.as<uint32_t>() + 6;
     uint32_t head_ready = 0xFFFFFFFFu, head_reps = 0;  // sweep whose head already runs on the side stream
     Pinned<uint32_t> h_nA;
     h_nA.bind(ctx, 10);
@@ -1363,6 +1382,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         }
     };
     const bool trace = std::getenv("PGX_TRACE") != nullptr;
+    const uint32_t side_grid = std::getenv("PGX_SIDE_GRID") ? (uint32_t)atoi(std::getenv("PGX_SIDE_GRID")) : 512u;  // experiment
     const auto t_loop0 = std::chrono::steady_clock::now();
     double t_resolve = 0.0, t_close = 0.0;
     uint64_t n_blocks = 0;
@@ -1400,8 +1420,6 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // it only depends on the sweep's position, so it can run ahead on the side stream
         auto sweep_head = [&](const SweepBuf &W, uint32_t hb0, uint32_t hnb, uint32_t hns, uint32_t n_table,
                               hipStream_t hs) -> int {
-            PGX_HIP(hipMemsetAsync(W.bi_cnt, 0, ((size_t)n_codes + 1) * 4, hs));
-            PGX_HIP(hipMemsetAsync(W.bi_fill, 0, (size_t)n_codes * 4, hs));
             PGX_HIP(hipMemsetAsync(W.nA, 0, 4, hs));
             {
                 ProfScope prof(ctx, "index_hist_kernel", hs);
@@ -1415,29 +1433,40 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             }
             {
                 ProfScope prof(ctx, "index_scatter_kernel", hs);
-                index_scatter_kernel<<<hns, 256, 0, hs>>>(DS, hb0, hns, hnb, W.bi_off, W.bi_fill, W.bi_ent);
+                index_scatter_kernel<<<hns, 256, 0, hs>>>(DS, hb0, hns, hnb, W.bi_off, W.bi_cnt, W.bi_ent);
             }
             LAUNCH_CHECK();
             if (n_table) {
                 ProfScope prof(ctx, "count_kernel<table>", hs);
                 auto kern = nt ? count_kernel<MODE_TABLE, true, 256> : count_kernel<MODE_TABLE, false, 256>;
                 // on the side stream leave room (LDS, wave slots) for the main stream's small kernels
-                kern<<<std::min(n_table, hs == st ? 4096u : 512u), 256, 0, hs>>>(
+                kern<<<std::min(n_table, hs == st ? 4096u : side_grid), 256, 0, hs>>>(
                     DS, d_rep_seq.as<uint32_t>(), nullptr, n_table, hb0, hns, hnb, W.bi_off, W.bi_ent,
                     d_aan.as<int32_t>(), nullptr, nullptr, W.pairsA, W.nA, pair_cap,
-                    d_visits.as<unsigned long long>(), d_rcvis, 0u);
+                    d_visits.as<unsigned long long>(), d_rcvis, nullptr, 0u);
                 LAUNCH_CHECK();
             }
             return PGX_OK;
         };
-        PGX_HIP(hipMemsetAsync(d_counters.p, 0, 32, st));
-        PGX_HIP(hipMemsetAsync(d_best, 0xFF, kBatchCap * 8, st));
-        if (both) PGX_HIP(hipMemsetAsync(d_rcvis, 0, kBatchCap * 8, st));
-        PGX_HIP(hipMemsetAsync(d_done, 0, 2 * kBatchCap, st));
+        sweep_init_kernel<<<kBatchCap / 256, 256, 0, st>>>(d_counters.as<uint32_t>(), d_best, both ? d_rcvis : nullptr, d_done);
+        LAUNCH_CHECK();
+        const bool own_head_done = head_ready == b0;  // the previous sweep ran this sweep's head on the side stream
+        const uint32_t own_head_reps = head_reps;
+        if (pipeline && b0 + sweep_cap < n) {
+            // next sweep's head on the side stream, overlapping this whole sweep: it depends on the
+            // representative list only (uploaded when the previous sweep closed)
+            const uint32_t hb0 = b0 + sweep_cap, hnb = std::min(sweep_cap, n - hb0);
+            PGX_HIP(hipEventRecord(ctx->ev_main, st));  // the representative list up to here is on the device
+            PGX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_main, 0));
+            int rc = sweep_head(sbuf[parity ^ 1], hb0, hnb, hnb, n_reps, ctx->stream2);
+            if (rc) return rc;
+            PGX_HIP(hipEventRecord(ctx->ev_side[parity ^ 1], ctx->stream2));
+            head_ready = hb0; head_reps = n_reps;
+        }
         uint32_t n_pre = 0;  // representatives the head has already been through
-        if (head_ready == b0) {  // the previous sweep ran this head on the side stream
+        if (own_head_done) {
             PGX_HIP(hipStreamWaitEvent(st, ctx->ev_side[parity], 0));
-            n_pre = head_reps;
+            n_pre = own_head_reps;
         } else {
             int rc = sweep_head(B, b0, nb, ns, n_reps, st);
             if (rc) return rc;
@@ -1449,7 +1478,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             kern<<<std::min(n_reps - n_pre, 4096u), 256, 0, st>>>(
                 DS, d_rep_seq.as<uint32_t>() + n_pre, nullptr, n_reps - n_pre, b0, ns, nb, B.bi_off, B.bi_ent,
                 d_aan.as<int32_t>(), nullptr, nullptr, B.pairsA, B.nA, pair_cap, d_visits.as<unsigned long long>(),
-                d_rcvis, n_pre);
+                d_rcvis, nullptr, n_pre);
             LAUNCH_CHECK();
         }
         // diag + align of a selection of pair records, enqueued on the stream
@@ -1476,18 +1505,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         };
         // phase A: against the representatives that exist already (fully on the device)
         if (n_reps) {
-            const PairSel selA{nullptr, d_nA, pair_cap, nullptr, 0, nullptr, b0, 0};
+            const PairSel selA{nullptr, d_nA, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0};
             int rc = evaluate(d_rep_seq.as<uint32_t>(), B.pairsA, selA, d_best, 0u, 0);
             if (rc) return rc;
-        }
-        if (pipeline && b0 + sweep_cap < n) {  // next sweep's head, overlapping this sweep's phase B
-            const uint32_t hb0 = b0 + sweep_cap, hnb = std::min(sweep_cap, n - hb0);
-            PGX_HIP(hipEventRecord(ctx->ev_main, st));  // the representative list up to here is on the device
-            PGX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_main, 0));
-            int rc = sweep_head(sbuf[parity ^ 1], hb0, hnb, hnb, n_reps, ctx->stream2);
-            if (rc) return rc;
-            PGX_HIP(hipEventRecord(ctx->ev_side[parity ^ 1], ctx->stream2));
-            head_ready = hb0; head_reps = n_reps;
         }
         // phase B: members without a representative, one block at a time. A block is
         // resolved exactly (all its in-block pairs are aligned, then the host walks it in
@@ -1495,19 +1515,20 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // only, so pair work stays close to what the one-by-one pass would do.
         for (uint32_t q = 0; q < nb; ++q) status[q] = ST_OPEN;
         uint32_t new_off = 0;  // new representatives of this sweep so far (staging offset)
-        // later queries against a list of new representatives already staged at d_new (on the device)
-        auto new_rep_pass = [&](const uint32_t *d_new, uint32_t nr) -> int {
-            snapshot_kernel<<<1, 1, 0, st>>>(d_nN, d_nN0);
+        // later queries against a list of new representatives
+        // (the list may live in page-locked host memory; its length comes from the device when
+        // `d_nr` is given, and the snapshot of the pair count was taken by the kernel before)
+        auto new_rep_pass = [&](const uint32_t *new_list, const uint32_t *d_nr, uint32_t nr) -> int {
             {
                 ProfScope prof(ctx, "count_kernel<new>", st);
                 auto kern = nt ? count_kernel<MODE_NEW, true, kCountWide> : count_kernel<MODE_NEW, false, kCountWide>;
-                kern<<<nr, kCountWide, 0, st>>>(DS, d_new, nullptr, nr, b0, ns, nb, B.bi_off,
+                kern<<<d_nr ? 512u : nr, kCountWide, 0, st>>>(DS, new_list, d_nr, nr, b0, ns, nb, B.bi_off,
                                          B.bi_ent, d_aan.as<int32_t>(), d_best, d_done,
                                          d_pairsN.as<Pair>(), d_nN, pair_cap, d_visits.as<unsigned long long>(),
-                                         d_rcvis, 0u);
+                                         d_rcvis, nullptr, 0u);
             }
             LAUNCH_CHECK();
-            const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, b0, 0};
+            const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0};
             return evaluate(nullptr, d_pairsN.as<Pair>(), selN, d_best, kNewBit, 0);
         };
         // Discovery: still-unassigned members that cannot have an earlier unassigned candidate are
@@ -1526,58 +1547,62 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                                                                 d_first.as<uint32_t>());
                 certain_kernel<<<(nb + 3) / 4, 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), d_blk, b0, both ? 1u : 0u,
                                                              epoch, d_first.as<uint32_t>(), d_aan.as<int32_t>(), d_done,
-                                                             d_new_list.as<uint32_t>(), d_blk + 1);
+                                                             d_new_list.as<uint32_t>(), d_ncertain, d_nN, d_nN0);
             }
             LAUNCH_CHECK();
-            PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
-            PGX_HIP(hipMemcpyAsync(h_new.p, d_new_list.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
-            PGX_HIP(spin_sync(st));
-            const uint32_t n_certain = h_cnt.p[5];
-            for (uint32_t i = 0; i < n_certain; ++i) status[h_new.p[i] - b0] = ST_REP;
-            if (n_certain) {
-                int rc = new_rep_pass(d_new_list.as<uint32_t>(), n_certain);
-                if (rc) return rc;
-                new_off = n_certain;
-            }
+            // no round trip: the pass takes the list and its length from the device; the host
+            // learns both with the first block's results
+            int rc = new_rep_pass(d_new_list.as<uint32_t>(), d_ncertain, 0);
+            if (rc) return rc;
         }
+        bool first_block = true;
         for (;;) {
             select_block_kernel<<<1, 1024, 0, st>>>(d_best, d_done, d_inblk, b0, nb, kBlockCap,
-                                                    d_blk_list.as<uint32_t>(), d_blk);
+                                                    d_blk_list.as<uint32_t>(), d_blk, d_nK,
+                                                    reinterpret_cast<unsigned long long *>(d_hascand));  // + has_cand, accepted = 0
             LAUNCH_CHECK();
-            PGX_HIP(hipMemsetAsync(d_nK, 0, 4, st));
             {
                 ProfScope prof(ctx, "count_kernel<block>", st);
                 auto kern = nt ? count_kernel<MODE_BLOCK, true, kCountWide> : count_kernel<MODE_BLOCK, false, kCountWide>;
                 kern<<<kBlockCap, kCountWide, 0, st>>>(
                     DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, B.bi_off, B.bi_ent,
-                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis, 0u);
+                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis,
+                    d_hascand, 0u);
             }
             LAUNCH_CHECK();
-            // A block member without an earlier in-block candidate is certainly a new
-            // representative; only pairs against those are evaluated up front. Whatever the
-            // in-order walk on the host still needs afterwards goes through follow-up rounds.
-            PGX_HIP(hipMemsetAsync(d_hascand, 0, 2 * kBatchCap, st));  // has_cand + accepted
-            mark_candidates_kernel<<<256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_nK, pair_cap_k, b0, n, d_hascand);
-            LAUNCH_CHECK();
+            // A block member without an earlier in-block candidate (has_cand clear) is certainly a
+            // new representative; only pairs against those are evaluated up front. Second round on
+            // the device: a member that has candidates but was accepted by none of the certain
+            // representatives is LIKELY a representative itself (an outlier of its family), so the
+            // pairs against those follow. Whatever the in-order walk on the host still needs
+            // afterwards goes through follow-up rounds.
             {
-                const PairSel selK{nullptr, d_nK, pair_cap_k, nullptr, 0, d_hascand, b0, 0};
+                const PairSel selK{nullptr, d_nK, pair_cap_k, nullptr, 0, nullptr, d_hascand, d_accepted, b0, 0};
                 int rc = evaluate(nullptr, d_pairsK.as<Pair>(), selK, nullptr, 0u, 0);
                 if (rc) return rc;
-            }
-            // second round on the device: pairs against likely (outlier) representatives
-            mark_accepted_kernel<<<256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_nK, pair_cap_k, b0, n, d_accepted);
-            likely_rep_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_hascand, d_accepted, nb, d_skip2);
-            LAUNCH_CHECK();
-            {
-                const PairSel selK2{nullptr, d_nK, pair_cap_k, nullptr, 0, d_skip2, b0, 1};
-                int rc = evaluate(nullptr, d_pairsK.as<Pair>(), selK2, nullptr, 0u, 0);
+                const PairSel selK2{nullptr, d_nK, pair_cap_k, nullptr, 0, d_hascand, d_accepted, nullptr, b0, 1};
+                rc = evaluate(nullptr, d_pairsK.as<Pair>(), selK2, nullptr, 0u, 0);
                 if (rc) return rc;
             }
-            // one round trip: counters, the block list and a prefix of the in-block pairs
-            PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
-            PGX_HIP(hipMemcpyAsync(h_blk.p, d_blk_list.p, (size_t)kBlockCap * 4, hipMemcpyDeviceToHost, st));
-            PGX_HIP(hipMemcpyAsync(hK.p, d_pairsK.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
+            // one round trip: counters, the block list, the in-block pairs (and, the first time,
+            // the certain representatives), written to host memory by one kernel
+            {
+                PubArgs pa{};
+                pa.seg[0] = {d_counters.as<uint32_t>(), h_cnt.p, nullptr, 8, 1, 8};
+                pa.seg[1] = {d_blk_list.as<uint32_t>(), h_blk.p, d_blk, 0, 1, kBlockCap};
+                pa.seg[2] = {d_pairsK.as<uint32_t>(), reinterpret_cast<uint32_t *>(hK.p), d_nK, 0, kPairWords, pair_cap_k};
+                pa.n = 3;
+                if (first_block) pa.seg[pa.n++] = {d_new_list.as<uint32_t>(), h_new.p, d_ncertain, 0, 1, kBatchCap};
+                publish_kernel<<<64, 256, 0, st>>>(pa);
+                LAUNCH_CHECK();
+            }
             PGX_HIP(spin_sync(st));
+            if (first_block) {
+                const uint32_t n_certain = h_cnt.p[6];
+                for (uint32_t i = 0; i < n_certain; ++i) status[h_new.p[i] - b0] = ST_REP;
+                new_off = n_certain;
+                first_block = false;
+            }
             const uint32_t n_blk = h_cnt.p[4], n_open = h_cnt.p[5], nK = h_cnt.p[2];
             if (h_cnt.p[1] > pair_cap || nK > pair_cap_k) {
                 pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u) in sweep at %u",
@@ -1585,11 +1610,6 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 return PGX_ERR_CAPACITY;
             }
             if (n_blk == 0) break;
-            if (nK > kPrefix) {
-                PGX_HIP(hipMemcpyAsync(hK.p + kPrefix, d_pairsK.as<Pair>() + kPrefix, (size_t)(nK - kPrefix) * sizeof(Pair),
-                                       hipMemcpyDeviceToHost, st));
-                PGX_HIP(spin_sync(st));
-            }
             // resolve the block in order: first accepted in-block representative by (minc, index)
             const auto t_r0 = std::chrono::steady_clock::now();
             ++n_blocks;
@@ -1653,7 +1673,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 std::copy(flight.begin(), flight.end(), h_list.p);
                 PGX_HIP(hipMemcpyAsync(d_list.p, h_list.p, (size_t)nl * 4, hipMemcpyHostToDevice, st));
                 {
-                    const PairSel selL{nullptr, nullptr, 0, d_list.as<uint32_t>(), nl, nullptr, b0, 0};
+                    const PairSel selL{nullptr, nullptr, 0, d_list.as<uint32_t>(), nl, nullptr, nullptr, nullptr, b0, 0};
                     int rc = evaluate(nullptr, d_pairsK.as<Pair>(), selL, nullptr, 0u, nl);
                     if (rc) return rc;
                 }
@@ -1687,23 +1707,32 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             // later queries against the block's new representatives (on the device)
             if (!new_reps.empty()) {
                 const uint32_t nr = (uint32_t)new_reps.size();
-                uint32_t *d_new = d_new_list.as<uint32_t>() + new_off;  // every block has its own staging range
-                std::copy(new_reps.begin(), new_reps.end(), h_new.p + new_off);
-                PGX_HIP(hipMemcpyAsync(d_new, h_new.p + new_off, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+                // the list stays in page-locked host memory (the pass reads each entry once); every
+                // block has its own range, so nothing in flight is overwritten
+                uint32_t *list = h_new.p + new_off;
+                std::copy(new_reps.begin(), new_reps.end(), list);
                 new_off += nr;
-                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb);
-                int rc = new_rep_pass(d_new, nr);
+                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, d_nN, d_nN0);
+                int rc = new_rep_pass(list, nullptr, nr);
                 if (rc) return rc;
             }
             if (n_open == n_blk) break;  // that was the last block
         }
         // ---- close the sweep ---------------------------------------------------------------
-        PGX_HIP(hipMemcpyAsync(h_cnt.p, d_counters.p, 32, hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipMemcpyAsync(h_best.p, d_best, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-        if (both) PGX_HIP(hipMemcpyAsync(h_rcvis.p, d_rcvis, (size_t)nb * 8, hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipMemcpyAsync(h_nA.p, d_nA, 4, hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipMemcpyAsync(hA.p, B.pairsA, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
-        PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)kPrefix * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        {   // counters, winners, and exactly the pair records that exist, in one launch
+            PubArgs pa{};
+            pa.seg[0] = {d_counters.as<uint32_t>(), h_cnt.p, nullptr, 8, 1, 8};
+            pa.seg[1] = {reinterpret_cast<const uint32_t *>(d_best), reinterpret_cast<uint32_t *>(h_best.p), nullptr, nb, 2, nb};
+            pa.seg[2] = {d_nA, h_nA.p, nullptr, 1, 1, 1};
+            pa.seg[3] = {reinterpret_cast<const uint32_t *>(B.pairsA), reinterpret_cast<uint32_t *>(hA.p), d_nA, 0, kPairWords,
+                         (uint32_t)std::min<size_t>(hA.cap, pair_cap)};
+            pa.seg[4] = {d_pairsN.as<uint32_t>(), reinterpret_cast<uint32_t *>(hN.p), d_nN, 0, kPairWords,
+                         (uint32_t)std::min<size_t>(hN.cap, pair_cap)};
+            pa.n = 5;
+            if (both) pa.seg[pa.n++] = {reinterpret_cast<const uint32_t *>(d_rcvis), reinterpret_cast<uint32_t *>(h_rcvis.p), nullptr, nb, 2, nb};
+            publish_kernel<<<64, 256, 0, st>>>(pa);
+            LAUNCH_CHECK();
+        }
         PGX_HIP(spin_sync(st));
         const uint32_t nA = h_nA.p[0], nN = h_cnt.p[1];
         if (nA > pair_cap || nN > pair_cap) {
@@ -1711,7 +1740,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                           nA, nN, pair_cap, b0);
             return PGX_ERR_CAPACITY;
         }
-        if (nA > kPrefix || nN > kPrefix) {
+        if (nA > hA.cap || nN > hN.cap) {  // the host buffers were too small: grow them and fetch again
             PGX_HIP(hA.reserve(nA)); PGX_HIP(hN.reserve(nN));  // (reserve keeps nothing: copy whole ranges again)
             if (nA) PGX_HIP(hipMemcpyAsync(hA.p, B.pairsA, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
             if (nN) PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)nN * sizeof(Pair), hipMemcpyDeviceToHost, st));
