@@ -320,6 +320,8 @@ __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t 
 // workgroups per CU); NEW and BLOCK have a few hundred table entries and are bound by the
 // latency of one workgroup's walk, so they run 1024 threads wide (kCountWide).
 enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2 };
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
 constexpr unsigned long long kNoBest = ~0ull;
 constexpr uint32_t kNewBit = 0x80000000u;
 constexpr uint32_t kLongMin = 16, kLongCap = 512;  // posting lists walked wave-cooperatively
@@ -341,18 +343,27 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
                                                    uint32_t pair_cap,
                                                    unsigned long long *__restrict__ visits,
                                                    unsigned long long *__restrict__ rc_visits,
-                                                   uint8_t *__restrict__ mark_out, uint32_t rep_base) {
-    __shared__ uint32_t cnt[kBatchCap];
-    __shared__ uint32_t minc[kBatchCap];
-    __shared__ uint32_t vis[NT ? kBatchCap : 1];
+                                                   uint8_t *__restrict__ mark_out, uint32_t rep_base, uint32_t tmin) {
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[kBatchCap];
+    __shared__ __attribute__((aligned(16))) uint32_t minc[kBatchCap];
+    __shared__ __attribute__((aligned(16))) uint32_t vis[NT ? kBatchCap : 4];
     // posting lists longer than kLongMin entries are queued and walked by whole waves with
     // coalesced loads (members of one family share most words: their lists have hundreds of entries)
     __shared__ uint32_t lq_lo[kLongCap], lq_meta[kLongCap], lq_code[kLongCap];
     __shared__ uint32_t n_long;
     __shared__ unsigned long long wg_visits;
     const uint32_t ntable = d_ntable ? *d_ntable : ntable_host;
+    // Nearly all counters an entry touches are chance hits of single words (a random word occurs
+    // somewhere in the batch more often than not), far below any query's threshold. Clearing and
+    // scanning therefore work on four counters per LDS access, and a group is only looked at one
+    // by one when its largest counter reaches the batch's smallest threshold `tmin`.
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u), sent4 = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
     for (uint32_t r = blockIdx.x; r < ntable; r += gridDim.x) {
-        for (uint32_t q = threadIdx.x; q < nb; q += THREADS) { cnt[q] = 0u; minc[q] = kSentinel; if (NT) vis[q] = 0u; }
+        for (uint32_t q4 = threadIdx.x * 4; q4 < kBatchCap; q4 += THREADS * 4) {
+            *reinterpret_cast<uint4 *>(&cnt[q4]) = zero4;
+            *reinterpret_cast<uint4 *>(&minc[q4]) = sent4;
+            if (NT) *reinterpret_cast<uint4 *>(&vis[q4]) = zero4;
+        }
         if (threadIdx.x == 0) { wg_visits = 0ull; n_long = 0u; }
         __syncthreads();
         const uint32_t k = table[r];
@@ -371,7 +382,10 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
         for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
             const uint32_t code = S.wcode[o + i];
             const uint32_t m = S.wmult[o + i];
-            const uint32_t lo = bi_off[code], hi = bi_off[code + 1];
+            // offsets code and code + 1 in ONE 8-byte gather (dword-aligned; the pass is bound by the
+            // number of random accesses, not by their bytes)
+            const u32x2 lh = *reinterpret_cast<const u32x2_a4 *>(bi_off + code);
+            const uint32_t lo = lh.x, hi = lh.y;
             if (hi - lo > kLongMin) {
                 const uint32_t slot = atomicAdd(&n_long, 1u);
                 if (slot < kLongCap) { lq_lo[slot] = lo; lq_meta[slot] = ((hi - lo) << 16) | m; lq_code[slot] = code; continue; }
@@ -396,19 +410,19 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
         }
         if (my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
         __syncthreads();
-        for (uint32_t q = threadIdx.x; q < nb; q += THREADS) {
+        auto finish = [&](uint32_t q) {  // counters of batch slot q -> candidate pair record
             const uint32_t c = cnt[q];
             const uint32_t ql = q >= nbq ? q - nbq : q;  // the query's local index; q >= nbq = reverse strand
             if (NT && (MODE == MODE_TABLE || MODE == MODE_NEW) && q >= nbq && vis[q])
                 atomicAdd(&rc_visits[ql], (unsigned long long)vis[q]);
-            if (c == 0u || (int32_t)c < req_aan[b0 + ql]) continue;
+            if (c == 0u || (int32_t)c < req_aan[b0 + ql]) return;
             if (MODE == MODE_NEW) {
-                if (qflag[ql]) continue;  // resolved inside a block already
+                if (qflag[ql]) return;  // resolved inside a block already
                 const unsigned long long bo = best[ql];
                 const unsigned long long hi = ((unsigned long long)(q >= nbq) << 63) | ((unsigned long long)minc[q] << 32);
-                if (bo != kNoBest && hi >= (bo & 0xFFFFFFFF00000000ull)) continue;
+                if (bo != kNoBest && hi >= (bo & 0xFFFFFFFF00000000ull)) return;
             }
-            if (MODE == MODE_BLOCK && !qflag[ql]) continue;  // not in the current block
+            if (MODE == MODE_BLOCK && !qflag[ql]) return;  // not in the current block
             if (MODE == MODE_BLOCK) mark_out[ql] = 1;        // this block member has an earlier in-block candidate
             const uint32_t slot = atomicAdd(n_pairs, 1u);
             if (slot < pair_cap) {
@@ -417,6 +431,14 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
                 p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
                 pairs[slot] = p;
             }
+        };
+        for (uint32_t q4 = threadIdx.x * 4; q4 < nb; q4 += THREADS * 4) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(&cnt[q4]);
+            const uint32_t mx = max(max(c.x, c.y), max(c.z, c.w));
+            // (nucleotide reverse-strand visits are attributed per query: every slot is looked at)
+            if (!(NT && MODE != MODE_BLOCK) && mx < tmin) continue;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) if (q4 + j < nb) finish(q4 + j);
         }
         __syncthreads();
         if ((MODE == MODE_TABLE || MODE == MODE_NEW) && threadIdx.x == 0 && wg_visits) atomicAdd(visits, wg_visits);
@@ -1418,6 +1440,13 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         uint32_t *d_nA = B.nA;
         // sweep head = index over the batch + the table pass against representatives [0, n_table);
         // it only depends on the sweep's position, so it can run ahead on the side stream
+        // smallest word threshold among a sweep's queries (a candidate needs at least one shared word)
+        auto min_threshold = [&](uint32_t q0, uint32_t nq) {
+            int32_t t = INT32_MAX;
+            for (uint32_t q = q0; q < q0 + nq; ++q) t = std::min(t, std::max(h_aan[q], 1));
+            return (uint32_t)t;
+        };
+        const uint32_t tmin = min_threshold(b0, nb);
         auto sweep_head = [&](const SweepBuf &W, uint32_t hb0, uint32_t hnb, uint32_t hns, uint32_t n_table,
                               hipStream_t hs) -> int {
             PGX_HIP(hipMemsetAsync(W.nA, 0, 4, hs));
@@ -1443,7 +1472,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 kern<<<std::min(n_table, hs == st ? 4096u : side_grid), 256, 0, hs>>>(
                     DS, d_rep_seq.as<uint32_t>(), nullptr, n_table, hb0, hns, hnb, W.bi_off, W.bi_ent,
                     d_aan.as<int32_t>(), nullptr, nullptr, W.pairsA, W.nA, pair_cap,
-                    d_visits.as<unsigned long long>(), d_rcvis, nullptr, 0u);
+                    d_visits.as<unsigned long long>(), d_rcvis, nullptr, 0u, min_threshold(hb0, hnb));
                 LAUNCH_CHECK();
             }
             return PGX_OK;
@@ -1478,7 +1507,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             kern<<<std::min(n_reps - n_pre, 4096u), 256, 0, st>>>(
                 DS, d_rep_seq.as<uint32_t>() + n_pre, nullptr, n_reps - n_pre, b0, ns, nb, B.bi_off, B.bi_ent,
                 d_aan.as<int32_t>(), nullptr, nullptr, B.pairsA, B.nA, pair_cap, d_visits.as<unsigned long long>(),
-                d_rcvis, nullptr, n_pre);
+                d_rcvis, nullptr, n_pre, tmin);
             LAUNCH_CHECK();
         }
         // diag + align of a selection of pair records, enqueued on the stream
@@ -1525,7 +1554,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 kern<<<d_nr ? 512u : nr, kCountWide, 0, st>>>(DS, new_list, d_nr, nr, b0, ns, nb, B.bi_off,
                                          B.bi_ent, d_aan.as<int32_t>(), d_best, d_done,
                                          d_pairsN.as<Pair>(), d_nN, pair_cap, d_visits.as<unsigned long long>(),
-                                         d_rcvis, nullptr, 0u);
+                                         d_rcvis, nullptr, 0u, tmin);
             }
             LAUNCH_CHECK();
             const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0};
@@ -1567,7 +1596,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 kern<<<kBlockCap, kCountWide, 0, st>>>(
                     DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, B.bi_off, B.bi_ent,
                     d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis,
-                    d_hascand, 0u);
+                    d_hascand, 0u, tmin);
             }
             LAUNCH_CHECK();
             // A block member without an earlier in-block candidate (has_cand clear) is certainly a
