@@ -37,6 +37,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <type_traits>
+#include <functional>
 #include <vector>
 
 #include "cluster_tables.h"
@@ -1409,6 +1410,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     double t_resolve = 0.0, t_close = 0.0;
     uint64_t n_blocks = 0;
     g_wait_s = 0.0;
+    std::function<int()> deferred;  // bookkeeping of the sweep before, see the close of a sweep
     for (uint32_t b0 = 0; b0 < n; b0 += sweep_cap) {
         const uint32_t nb = std::min(sweep_cap, n - b0);  // queries of this sweep
         const uint32_t ns = both ? 2 * nb : nb;           // batch slots: + one per reverse complement
@@ -1481,17 +1483,11 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         LAUNCH_CHECK();
         const bool own_head_done = head_ready == b0;  // the previous sweep ran this sweep's head on the side stream
         const uint32_t own_head_reps = head_reps;
-        if (pipeline && b0 + sweep_cap < n) {
-            // next sweep's head on the side stream, overlapping this whole sweep: it depends on the
-            // representative list only (uploaded when the previous sweep closed)
-            const uint32_t hb0 = b0 + sweep_cap, hnb = std::min(sweep_cap, n - hb0);
-            PGX_HIP(hipEventRecord(ctx->ev_main, st));  // the representative list up to here is on the device
-            PGX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_main, 0));
-            int rc = sweep_head(sbuf[parity ^ 1], hb0, hnb, hnb, n_reps, ctx->stream2);
-            if (rc) return rc;
-            PGX_HIP(hipEventRecord(ctx->ev_side[parity ^ 1], ctx->stream2));
-            head_ready = hb0; head_reps = n_reps;
-        }
+        // The next sweep's head runs on the side stream, overlapping this whole sweep: it depends on the
+        // representative list only (uploaded when the previous sweep closed). The event marks that
+        // point; the head itself is enqueued after this sweep's first kernels so they start at once.
+        const bool want_head = pipeline && b0 + sweep_cap < n;
+        if (want_head) PGX_HIP(hipEventRecord(ctx->ev_main, st));
         uint32_t n_pre = 0;  // representatives the head has already been through
         if (own_head_done) {
             PGX_HIP(hipStreamWaitEvent(st, ctx->ev_side[parity], 0));
@@ -1502,9 +1498,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             n_pre = n_reps;
         }
         if (n_reps > n_pre) {  // representatives created after the head was enqueued (the previous sweep's)
-            ProfScope prof(ctx, "count_kernel<table>", st);
-            auto kern = nt ? count_kernel<MODE_TABLE, true, 256> : count_kernel<MODE_TABLE, false, 256>;
-            kern<<<std::min(n_reps - n_pre, 4096u), 256, 0, st>>>(
+            ProfScope prof(ctx, "count_kernel<table>", st);  // a few hundred entries: latency-bound, so wide
+            auto kern = nt ? count_kernel<MODE_TABLE, true, kCountWide> : count_kernel<MODE_TABLE, false, kCountWide>;
+            kern<<<std::min(n_reps - n_pre, 4096u), kCountWide, 0, st>>>(
                 DS, d_rep_seq.as<uint32_t>() + n_pre, nullptr, n_reps - n_pre, b0, ns, nb, B.bi_off, B.bi_ent,
                 d_aan.as<int32_t>(), nullptr, nullptr, B.pairsA, B.nA, pair_cap, d_visits.as<unsigned long long>(),
                 d_rcvis, nullptr, n_pre, tmin);
@@ -1538,11 +1534,18 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             int rc = evaluate(d_rep_seq.as<uint32_t>(), B.pairsA, selA, d_best, 0u, 0);
             if (rc) return rc;
         }
+        if (want_head) {
+            const uint32_t hb0 = b0 + sweep_cap, hnb = std::min(sweep_cap, n - hb0);
+            PGX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_main, 0));
+            int rc = sweep_head(sbuf[parity ^ 1], hb0, hnb, hnb, n_reps, ctx->stream2);
+            if (rc) return rc;
+            PGX_HIP(hipEventRecord(ctx->ev_side[parity ^ 1], ctx->stream2));
+            head_ready = hb0; head_reps = n_reps;
+        }
         // phase B: members without a representative, one block at a time. A block is
         // resolved exactly (all its in-block pairs are aligned, then the host walks it in
         // order); every later query is then compared with the block's NEW representatives
         // only, so pair work stays close to what the one-by-one pass would do.
-        for (uint32_t q = 0; q < nb; ++q) status[q] = ST_OPEN;
         uint32_t new_off = 0;  // new representatives of this sweep so far (staging offset)
         // later queries against a list of new representatives
         // (the list may live in page-locked host memory; its length comes from the device when
@@ -1624,6 +1627,12 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 if (first_block) pa.seg[pa.n++] = {d_new_list.as<uint32_t>(), h_new.p, d_ncertain, 0, 1, kBatchCap};
                 publish_kernel<<<64, 256, 0, st>>>(pa);
                 LAUNCH_CHECK();
+            }
+            if (first_block) {
+                // everything up to here was enqueued without looking at results: the previous sweep's
+                // bookkeeping runs now, behind that work, and only then is the member state reset
+                if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
+                for (uint32_t q = 0; q < nb; ++q) status[q] = ST_OPEN;
             }
             PGX_HIP(spin_sync(st));
             if (first_block) {
@@ -1801,31 +1810,38 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         for (uint32_t q = 0; q < nb; ++q)
             if (status[q] == ST_MEMBER)
                 cluster_of[b0 + q] = won_new[q] ? cluster_of[member_of[q]] : (int32_t)member_of[q];
-        // identities of the winners + the candidates the one-by-one pass would have examined
-        auto examine = [&](const Pair &p, bool is_new, uint32_t len2) {
-            const uint32_t k = real(p.q), q = k - b0;
-            if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) return false;
-            const unsigned long long key = pair_key(p, is_new);
-            // the one-by-one pass examines candidates in key order up to and including the winner
-            if (status[q] == ST_REP || key <= winner_key[q]) {
-                S.filter_pairs++;
-                if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
-                    S.aligned_pairs++;
-                    S.aligned_rep_len += len2;
-                    S.dp_cells += (uint64_t)h_len[k] * (uint64_t)(p.band_right - p.band_left + 1);
+        // identities of the winners + the candidates the one-by-one pass would have examined: pure
+        // bookkeeping on the host copies, deferred until the next sweep's first kernels are enqueued
+        {
+            const Pair *pA = hA.p, *pN = hN.p;
+            deferred = [&, b0, nA, nN, pA, pN]() -> int {
+                auto examine = [&](const Pair &p, bool is_new, uint32_t len2) {
+                    const uint32_t k = real(p.q), q = k - b0;
+                    if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) return false;
+                    const unsigned long long key = pair_key(p, is_new);
+                    // the one-by-one pass examines candidates in key order up to and including the winner
+                    if (status[q] == ST_REP || key <= winner_key[q]) {
+                        S.filter_pairs++;
+                        if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
+                            S.aligned_pairs++;
+                            S.aligned_rep_len += len2;
+                            S.dp_cells += (uint64_t)h_len[k] * (uint64_t)(p.band_right - p.band_left + 1);
+                        }
+                        if ((p.flags & F_ACCEPT) && status[q] == ST_MEMBER && key == winner_key[q]) iden_of[k] = p.iden;
+                    }
+                    return true;
+                };
+                account(pA, nA, true);
+                account(pN, nN, false);
+                bool fits = true;
+                for (uint32_t i = 0; i < nA; ++i) fits &= examine(pA[i], false, h_len[rep_seq[pA[i].r]]);
+                for (uint32_t i = 0; i < nN; ++i) fits &= examine(pN[i], true, h_len[pN[i].r]);
+                if (!fits) {
+                    pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
+                    return PGX_ERR_CAPACITY;
                 }
-                if ((p.flags & F_ACCEPT) && status[q] == ST_MEMBER && key == winner_key[q]) iden_of[k] = p.iden;
-            }
-            return true;
-        };
-        account(hA.p, nA, true);
-        account(hN.p, nN, false);
-        bool fits = true;
-        for (uint32_t i = 0; i < nA; ++i) fits &= examine(hA.p[i], false, h_len[rep_seq[hA.p[i].r]]);
-        for (uint32_t i = 0; i < nN; ++i) fits &= examine(hN.p[i], true, h_len[hN.p[i].r]);
-        if (!fits) {
-            pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
-            return PGX_ERR_CAPACITY;
+                return PGX_OK;
+            };
         }
         if (rep_seq.size() > n_reps) {
             // staged through a pinned buffer of its own parity so the next sweep can start at once
@@ -1841,6 +1857,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                     (unsigned long long)(n_blocks - blocks_before), rep_seq.size() - n_reps, rep_seq.size(), nA, nN,
                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sweep0).count());
     }
+    if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
     if (trace)
         fprintf(stderr, "[pgx] sweeps %llu blocks %llu (+%llu follow-up rounds): loop %.1f ms = wait %.1f + block resolve %.1f + sweep close %.1f + "
                 "enqueue/other %.1f\n", (unsigned long long)S.sweeps, (unsigned long long)n_blocks, (unsigned long long)n_rounds,

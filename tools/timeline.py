@@ -46,6 +46,14 @@ def main():
     gg['sum'] /= 1e3
     print('idle before (sum ms, n, mean us):  total %.1f ms' % (gap.sum() / 1e3))
     print(gg.head(12).to_string(float_format=lambda x: '%.1f' % x))
+    if len(sys.argv) > 3:   # dump the launches of sweeps [N, N + 1): from the N-th sweep_init_kernel on
+        n_sw = int(sys.argv[3])
+        starts = d[d.k == 'sweep_init_kernel'].Start_Timestamp.values
+        a, b = starts[n_sw], starts[n_sw + 2]
+        w = d[(d.Start_Timestamp >= a - 200000) & (d.Start_Timestamp < b)]
+        for _, r in w.iterrows():
+            print('%9.1f %9.1f %s %-28s %7.1f us  wg %d' % ((r.Start_Timestamp - a) / 1e3, (r.End_Timestamp - a) / 1e3,
+                  'M' if r.Queue_Id == main_q else 's', r.k, r.dur, r.Grid_Size_X // r.Workgroup_Size_X))
 
 
 if __name__ == '__main__':
