@@ -1233,7 +1233,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         max_batch_words = std::max<uint64_t>(max_batch_words, (h_off[b1] - h_off[b0]) * (both ? 2 : 1));
     }
     const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsCap;
-    const uint32_t diag_grid = 2048, align_grid = 1024;
+    const uint32_t diag_grid = 4096, align_grid = 1024;
     const uint32_t gs_stride = 3u * (kMaxLen + 1);
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
@@ -1485,7 +1485,8 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         const uint32_t own_head_reps = head_reps;
         // The next sweep's head runs on the side stream, overlapping this whole sweep: it depends on the
         // representative list only (uploaded when the previous sweep closed). The event marks that
-        // point; the head itself is enqueued after this sweep's first kernels so they start at once.
+        // point; the head itself is enqueued once this sweep's kernels up to the first block's
+        // results are in the queue, so the main stream never waits for the host to get to them.
         const bool want_head = pipeline && b0 + sweep_cap < n;
         if (want_head) PGX_HIP(hipEventRecord(ctx->ev_main, st));
         uint32_t n_pre = 0;  // representatives the head has already been through
@@ -1534,14 +1535,18 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             int rc = evaluate(d_rep_seq.as<uint32_t>(), B.pairsA, selA, d_best, 0u, 0);
             if (rc) return rc;
         }
-        if (want_head) {
+        bool head_enqueued = !want_head;
+        auto enqueue_head = [&]() -> int {
+            if (head_enqueued) return PGX_OK;
+            head_enqueued = true;
             const uint32_t hb0 = b0 + sweep_cap, hnb = std::min(sweep_cap, n - hb0);
             PGX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_main, 0));
             int rc = sweep_head(sbuf[parity ^ 1], hb0, hnb, hnb, n_reps, ctx->stream2);
             if (rc) return rc;
             PGX_HIP(hipEventRecord(ctx->ev_side[parity ^ 1], ctx->stream2));
             head_ready = hb0; head_reps = n_reps;
-        }
+            return PGX_OK;
+        };
         // phase B: members without a representative, one block at a time. A block is
         // resolved exactly (all its in-block pairs are aligned, then the host walks it in
         // order); every later query is then compared with the block's NEW representatives
@@ -1629,6 +1634,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 LAUNCH_CHECK();
             }
             if (first_block) {
+                { int rc = enqueue_head(); if (rc) return rc; }
                 // everything up to here was enqueued without looking at results: the previous sweep's
                 // bookkeeping runs now, behind that work, and only then is the member state reset
                 if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
