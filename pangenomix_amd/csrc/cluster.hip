@@ -870,20 +870,23 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
                                                      const int32_t *__restrict__ req_aa1, double cluster_thd,
                                                      uint32_t b0, unsigned long long *__restrict__ best,
                                                      uint32_t key_flag) {
-    __shared__ int32_t tab[4][kNAA1 * kNAA1];
-    __shared__ uint32_t seqbuf[16][kA16Slot / 4];
+    // substitution score + centre bonus in key form (value * 4 + 2, see the interior rows) and the
+    // identity bit, one 8-byte entry per residue pair and bonus class
+    __shared__ int2 tab[4][kNAA1 * kNAA1];
+    __shared__ uint32_t seqbuf[16 * (kA16Slot / 4) + 32];  // + padding: lanes outside a band may read a few bytes past the last slot
     // one wave per SIMD, bound by its own dependent chain: issue ahead of the side stream's table pass
     __builtin_amdgcn_s_setprio(3);
     for (int c = threadIdx.x; c < 4 * kNAA1 * kNAA1; c += 256) {
         const int cc = c % (kNAA1 * kNAA1);
         const int s = S.nt ? (cc / kNAA1 == cc % kNAA1 ? 2 : -2) : (int)kBlosum62_dev[cc];
-        tab[c / (kNAA1 * kNAA1)][c % (kNAA1 * kNAA1)] = s * (1 << kScaleShift) + (s > 0 ? c / (kNAA1 * kNAA1) + 1 : 0);
+        const int v = s * (1 << kScaleShift) + (s > 0 ? c / (kNAA1 * kNAA1) + 1 : 0);
+        tab[c / (kNAA1 * kNAA1)][cc] = make_int2(v * 4 + 2, cc / kNAA1 == cc % kNAA1);
     }
     __syncthreads();
     const uint32_t n = sel_count(sel);
     const int lane = threadIdx.x & 63, gl = lane & 15;
     const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
-    const uint8_t *sb = reinterpret_cast<const uint8_t *>(seqbuf[slot]);
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(seqbuf + slot * (kA16Slot / 4));
     const int gap = (S.nt ? -6 : kGapOpen) * (1 << kScaleShift), ext = (S.nt ? -1 : kGapExt) * (1 << kScaleShift);
     constexpr int kNever = INT32_MIN / 2;
 
@@ -908,7 +911,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
         if (fast) {
             const uint32_t *p1 = S.pk + S.pk_off[k1], *p2 = S.pk + S.pk_off[k2];
             const int w1 = (len1 + 5) / 6, w2 = (len2 + 5) / 6;
-            uint8_t *sbw = reinterpret_cast<uint8_t *>(seqbuf[slot]);
+            uint8_t *sbw = reinterpret_cast<uint8_t *>(seqbuf + slot * (kA16Slot / 4));
             o2 = (6 * w1 + 7) & ~7;
             for (int w = gl; w < w1; w += 16) {
                 const uint32_t x = p1[w];
@@ -927,7 +930,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
         const int bs0 = ext * (if0 > 0 ? if0 : c0 + bl), bs1 = ext * (if1 > 0 ? if1 : c1 + bl);
         const int maxd = pr.band_center - bl;
         const int d0 = c0 > maxd ? c0 - maxd : maxd - c0, d1 = c1 > maxd ? c1 - maxd : maxd - c1;
-        const int32_t *t0 = tab[3 - (d0 & 3)], *t1 = tab[3 - (d1 & 3)];   // bonus = 4 - (dist & 3)
+        const int2 *t0 = tab[3 - (d0 & 3)], *t1 = tab[3 - (d1 & 3)];   // bonus = 4 - (dist & 3)
         const bool left0 = c0 > 0, top0 = c0 + 1 < bw, top1 = c1 + 1 < bw;
         const int trip = fast ? len1 + ((bw + 1) >> 1) : 0;                // rows 0..len1 for lanes 0..nl-1
 
@@ -936,54 +939,46 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
         auto res2 = [&](int j) { return (int)sb[o2 + min(max(j - 1, 0), len2 - 1)]; };  // representative residue of column j
         int i = -gl;                                 // row of this lane in iteration tau: i = tau - gl
         int ci = res1(i), cje = res2(c0 + i + bl), cjo = res2(c1 + i + bl);
-        int se = t0[ci * kNAA1 + cje], so = t1[ci * kNAA1 + cjo];
-        int me = ci == cje, mo = ci == cjo;
+        int2 te = t0[ci * kNAA1 + cje], to = t1[ci * kNAA1 + cjo];   // {key-form score, match} of the row's two cells
         int sc0 = 0, m0 = 0, sc1 = 0, m1 = 0;       // last cell of the even / odd column: score, iden << 2 | back
 
-        // One row of the wavefront for this lane's two columns. INTERIOR = every live column of
-        // the wave is strictly inside its row range (no border cell, no last row/column, nothing
-        // starts or ends), so all range logic drops out of the dependent chain.
-        auto row = [&](int tau, auto interior) {
-            constexpr bool INTERIOR = decltype(interior)::value;
+        // One BORDER-AWARE row of the wavefront for this lane's two columns: first / last rows of
+        // a column, forced border cells, end gaps. Used before and after the interior rows.
+        auto row = [&](int tau) {
             const int ci_n = res1(i + 1), cjo_n = res2(c1 + i + 1 + bl);   // operands of the next row
             const int cje_n = cjo;                                         // j_even(tau + 1) == j_odd(tau)
+            const int se = te.x >> 2, so = to.x >> 2, me = te.y, mo = to.y;
             const int l_sc = dpp_row_shr1(sc1), l_m = dpp_row_shr1(m1);
             {   // ---- even column: cell (i, c0) ----
-                const int g0 = INTERIOR ? gap : (i == ie0 ? ext : gap);
+                const int g0 = i == ie0 ? ext : gap;
                 int bst = sc0 + se, bm = ((m0 >> 2) + me) << 2 | BK_DIAG;
                 const int ls = left0 ? l_sc + ((l_m & 3) == BK_LEFT ? ext : g0) : kNever;
                 if (ls > bst) { bst = ls; bm = (l_m & ~3) | BK_LEFT; }
                 const int ts = top0 ? sc1 + ((m1 & 3) == BK_TOP ? ext : g0) : kNever;
                 if (ts > bst) { bst = ts; bm = (m1 & ~3) | BK_TOP; }
-                if (INTERIOR) { if (v0) { sc0 = bst; m0 = bm; } }
-                else {
-                    if (i == if0) { bst = bs0; bm = BK_NONE; }
-                    if (v0 && tau < trip && i >= if0 && i <= ie0) { sc0 = bst; m0 = bm; }
-                }
+                if (i == if0) { bst = bs0; bm = BK_NONE; }
+                if (v0 && tau < trip && i >= if0 && i <= ie0) { sc0 = bst; m0 = bm; }
             }
             const int r_sc = dpp_row_shl1(sc0), r_m = dpp_row_shl1(m0);
             {   // ---- odd column: cell (i, c1) ----
-                const int g0 = INTERIOR ? gap : (i == ie1 ? ext : gap);
+                const int g0 = i == ie1 ? ext : gap;
                 int bst = sc1 + so, bm = ((m1 >> 2) + mo) << 2 | BK_DIAG;
                 const int ls = sc0 + ((m0 & 3) == BK_LEFT ? ext : g0);
                 if (ls > bst) { bst = ls; bm = (m0 & ~3) | BK_LEFT; }
                 const int ts = top1 ? r_sc + ((r_m & 3) == BK_TOP ? ext : g0) : kNever;
                 if (ts > bst) { bst = ts; bm = (r_m & ~3) | BK_TOP; }
-                if (INTERIOR) { if (v1) { sc1 = bst; m1 = bm; } }
-                else {
-                    if (i == if1) { bst = bs1; bm = BK_NONE; }
-                    if (v1 && tau < trip && i >= if1 && i <= ie1) { sc1 = bst; m1 = bm; }
-                }
+                if (i == if1) { bst = bs1; bm = BK_NONE; }
+                if (v1 && tau < trip && i >= if1 && i <= ie1) { sc1 = bst; m1 = bm; }
             }
             // keep the next row's table look-ups (which wait for the residues read above) behind
             // the DP arithmetic, so the LDS latency overlaps it
             __builtin_amdgcn_sched_barrier(0);
             cje = cje_n; cjo = cjo_n; ci = ci_n;
-            se = t0[ci * kNAA1 + cje]; so = t1[ci * kNAA1 + cjo];
-            me = ci == cje; mo = ci == cjo;
+            te = t0[ci * kNAA1 + cje]; to = t1[ci * kNAA1 + cjo];
             ++i;
         };
         // interior range of the wave: [lo, hi) = rows where every live lane has both cells interior
+        // (no border cell, no last row / column, nothing starts or ends)
         int lo = 0, hi = INT32_MAX, wtrip = trip;
         if (fast && v0) {
             lo = max(if0, v1 ? if1 : 0) + gl + 1;
@@ -992,11 +987,80 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
         for (int d = 32; d > 0; d >>= 1) {
             lo = max(lo, __shfl_xor(lo, d)); hi = min(hi, __shfl_xor(hi, d)); wtrip = max(wtrip, __shfl_xor(wtrip, d));
         }
-        lo = min(lo, wtrip); hi = min(hi, wtrip);
+        // (the three bounds are wave-uniform by construction: keep them, and the loops, scalar)
+        wtrip = __builtin_amdgcn_readfirstlane(wtrip);
+        lo = __builtin_amdgcn_readfirstlane(min(lo, wtrip)); hi = __builtin_amdgcn_readfirstlane(min(hi, wtrip));
         int tau = 0;
-        for (; tau < lo; ++tau) row(tau, std::false_type{});
-        for (; tau < hi; ++tau) row(tau, std::true_type{});
-        for (; tau < wtrip; ++tau) row(tau, std::false_type{});
+        for (; tau < lo; ++tau) row(tau);
+        if (tau < hi) {
+            // ---- interior rows in KEY FORM ----------------------------------------------------
+            // Nearly all rows. A cell is K = score * 4 + code with code 2 = diagonal, 1 = left,
+            // 0 = top, so ONE max3 over the three candidate keys picks the winner with the
+            // reference's tie order (diagonal > left > top). Every cell also publishes the keys it
+            // offers as a left source (XL: + extension if it came from the left itself, else + open,
+            // code 1) and as a top source (XT, code 0), so a consumer spends no instruction on its
+            // neighbours' back pointers. Columns outside the band offer kNeverK for ever, which
+            // replaces all per-cell validity tests; identities travel beside the keys.
+            // Keys are kept biased by 2^31 and compared unsigned, so that 0 is "never": what a DPP
+            // read past the pair's 16 lanes delivers by itself (bound_ctrl), and what `& live` leaves.
+            constexpr uint32_t kBias = 0x80000000u;
+            uint32_t G1 = (uint32_t)(gap * 4 + 1), E1 = (uint32_t)(ext * 4 + 1), G0 = (uint32_t)(gap * 4), E0 = (uint32_t)(ext * 4);
+            // (held in vector registers: a select between two scalar constants under a scalar mask
+            // would have to re-materialise one of them on every row)
+            asm volatile("" : "+v"(G1), "+v"(E1), "+v"(G0), "+v"(E0));
+            const uint32_t live0 = v0 ? ~0u : 0u, live1 = v1 ? ~0u : 0u;
+            auto to_key = [&](int sc, int m, uint32_t live, uint32_t &K, uint32_t &N, uint32_t &XL, uint32_t &XT) {
+                const uint32_t Kc = (uint32_t)(sc * 4) + kBias;
+                const int b = m & 3;
+                K = Kc | (b == BK_LEFT ? 1u : (b == BK_TOP ? 0u : 2u));
+                N = (uint32_t)(m >> 2);
+                XL = (Kc + (b == BK_LEFT ? E1 : G1)) & live;
+                XT = (Kc + (b == BK_TOP ? E0 : G0)) & live;
+            };
+            uint32_t K0, N0, XL0, XT0, K1, N1, XL1, XT1;
+            to_key(sc0, m0, live0, K0, N0, XL0, XT0);
+            to_key(sc1, m1, live1, K1, N1, XL1, XT1);
+            // LDS byte addresses of the NEXT row's residues, advanced by one per row (no clamping: live
+            // cells are inside both sequences on interior rows, other lanes read padding or neighbours)
+            const uint8_t *a1 = sb + o1 + i, *a2 = sb + o2 + c1 + i + bl;
+            for (; tau < hi; ++tau) {
+                const int ci_n = *a1, cjo_n = *a2;
+                const int cje_n = cjo;
+                ++a1; ++a2;
+                {   // ---- even column: left = lane g-1's odd cell, top = own odd cell (both of the step before) ----
+                    const uint32_t lXL = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)XL1, 0x111, 0xF, 0xF, true);
+                    const uint32_t lN = (uint32_t)dpp_row_shr1((int)N1);
+                    const uint32_t K = max(max((K0 & ~3u) + (uint32_t)te.x, lXL), XT1);
+                    const uint32_t b = K & 3u, Kc = K & ~3u;
+                    N0 = b == 1u ? lN : (b == 0u ? N1 : N0 + (uint32_t)te.y);
+                    K0 = K;
+                    XL0 = (Kc + (b == 1u ? E1 : G1)) & live0; XT0 = (Kc + (b == 0u ? E0 : G0)) & live0;
+                }
+                {   // ---- odd column: left = own even cell, top = lane g+1's even cell (both of this step) ----
+                    const uint32_t rXT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)XT0, 0x101, 0xF, 0xF, true);
+                    const uint32_t rN = (uint32_t)dpp_row_shl1((int)N0);
+                    const uint32_t K = max(max((K1 & ~3u) + (uint32_t)to.x, XL0), rXT);
+                    const uint32_t b = K & 3u, Kc = K & ~3u;
+                    N1 = b == 1u ? N0 : (b == 0u ? rN : N1 + (uint32_t)to.y);
+                    K1 = K;
+                    XL1 = (Kc + (b == 1u ? E1 : G1)) & live1; XT1 = (Kc + (b == 0u ? E0 : G0)) & live1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cje = cje_n; cjo = cjo_n; ci = ci_n;
+                te = t0[ci * kNAA1 + cje]; to = t1[ci * kNAA1 + cjo];
+                ++i;
+            }
+            // back to score / (identities << 2 | back pointer) for the closing rows (from the keys
+            // alone: no comparison result is carried out of the loop)
+            asm volatile("" : "+v"(K0), "+v"(K1));
+            auto from_key = [&](uint32_t K, uint32_t N, int &sc, int &m) {
+                sc = (int)(K - kBias) >> 2;
+                m = (int)(N << 2) | ((K & 3u) == 1u ? BK_LEFT : ((K & 3u) == 0u ? BK_TOP : BK_DIAG));
+            };
+            if (v0) from_key(K0, N0, sc0, m0);
+            if (v1) from_key(K1, N1, sc1, m1);
+        }
+        for (; tau < wtrip; ++tau) row(tau);
         // ---- end cell = last cell of its column (see band_align_wave) ----------------------
         int ce;
         if (len2 - bl < len1) ce = 0;
