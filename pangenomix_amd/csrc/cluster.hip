@@ -861,6 +861,15 @@ constexpr int kScaleShift = 14;
 __device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
 __device__ __forceinline__ int dpp_row_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
 
+// lane-wise select under a lane mask, pinned to one v_cndmask (the compiler otherwise turns
+// chains of selects in the alignment's inner loop into branches)
+__device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t if_set, uint32_t if_clear) {
+    uint32_t d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return d;
+}
+__device__ __forceinline__ uint64_t lanes_equal(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32 /* ICMP_EQ */); }
+
 __device__ __forceinline__ bool pair_is_wide(int len1, int len2, int bl, int br) {
     return len1 + len2 > kA16MaxSum || br - bl + 1 > 32;
 }
@@ -919,7 +928,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
             }
             for (int w = gl; w < w2; w += 16) {
                 const uint32_t x = p2[w];
-                for (int t = 0; t < 6; ++t) sbw[o2 + 6 * w + t] = (uint8_t)((x >> (5 * t)) & 31u);
+                for (int t = 0; t < 6; ++t) sbw[o2 + 6 * w + t] = (uint8_t)(((x >> (5 * t)) & 31u) << 3);  // * 8: a table offset
             }
         }
         // ---- per-lane geometry of its two band columns -------------------------------------
@@ -936,10 +945,14 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
 
         // residues / table entries are fetched one row ahead
         auto res1 = [&](int i) { return (int)sb[o1 + max(i - 1, 0)]; };       // query residue of row i
-        auto res2 = [&](int j) { return (int)sb[o2 + min(max(j - 1, 0), len2 - 1)]; };  // representative residue of column j
+        auto res2 = [&](int j) { return (int)sb[o2 + min(max(j - 1, 0), len2 - 1)]; };  // representative residue of column j (* 8)
+        auto entry = [](const int2 *t, int c_query, int c_rep8) {  // table entry of a residue pair
+            return *reinterpret_cast<const int2 *>(__builtin_assume_aligned(
+                reinterpret_cast<const char *>(t) + c_query * (kNAA1 * 8) + c_rep8, 8));
+        };
         int i = -gl;                                 // row of this lane in iteration tau: i = tau - gl
         int ci = res1(i), cje = res2(c0 + i + bl), cjo = res2(c1 + i + bl);
-        int2 te = t0[ci * kNAA1 + cje], to = t1[ci * kNAA1 + cjo];   // {key-form score, match} of the row's two cells
+        int2 te = entry(t0, ci, cje), to = entry(t1, ci, cjo);   // {key-form score, match} of the row's two cells
         int sc0 = 0, m0 = 0, sc1 = 0, m1 = 0;       // last cell of the even / odd column: score, iden << 2 | back
 
         // One BORDER-AWARE row of the wavefront for this lane's two columns: first / last rows of
@@ -974,7 +987,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
             // the DP arithmetic, so the LDS latency overlaps it
             __builtin_amdgcn_sched_barrier(0);
             cje = cje_n; cjo = cjo_n; ci = ci_n;
-            te = t0[ci * kNAA1 + cje]; to = t1[ci * kNAA1 + cjo];
+            te = entry(t0, ci, cje); to = entry(t1, ci, cjo);
             ++i;
         };
         // interior range of the wave: [lo, hi) = rows where every live lane has both cells interior
@@ -1023,7 +1036,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
             // LDS byte addresses of the NEXT row's residues, advanced by one per row (no clamping: live
             // cells are inside both sequences on interior rows, other lanes read padding or neighbours)
             const uint8_t *a1 = sb + o1 + i, *a2 = sb + o2 + c1 + i + bl;
-            for (; tau < hi; ++tau) {
+            auto step = [&]() {
                 const int ci_n = *a1, cjo_n = *a2;
                 const int cje_n = cjo;
                 ++a1; ++a2;
@@ -1032,24 +1045,27 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
                     const uint32_t lN = (uint32_t)dpp_row_shr1((int)N1);
                     const uint32_t K = max(max((K0 & ~3u) + (uint32_t)te.x, lXL), XT1);
                     const uint32_t b = K & 3u, Kc = K & ~3u;
-                    N0 = b == 1u ? lN : (b == 0u ? N1 : N0 + (uint32_t)te.y);
+                    const uint64_t isL = lanes_equal(b, 1u), isT = lanes_equal(b, 0u);
+                    N0 = lane_select(isL, lN, lane_select(isT, N1, N0 + (uint32_t)te.y));
                     K0 = K;
-                    XL0 = (Kc + (b == 1u ? E1 : G1)) & live0; XT0 = (Kc + (b == 0u ? E0 : G0)) & live0;
+                    XL0 = (Kc + lane_select(isL, E1, G1)) & live0; XT0 = (Kc + lane_select(isT, E0, G0)) & live0;
                 }
                 {   // ---- odd column: left = own even cell, top = lane g+1's even cell (both of this step) ----
                     const uint32_t rXT = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)XT0, 0x101, 0xF, 0xF, true);
                     const uint32_t rN = (uint32_t)dpp_row_shl1((int)N0);
                     const uint32_t K = max(max((K1 & ~3u) + (uint32_t)to.x, XL0), rXT);
                     const uint32_t b = K & 3u, Kc = K & ~3u;
-                    N1 = b == 1u ? N0 : (b == 0u ? rN : N1 + (uint32_t)to.y);
+                    const uint64_t isL = lanes_equal(b, 1u), isT = lanes_equal(b, 0u);
+                    N1 = lane_select(isL, N0, lane_select(isT, rN, N1 + (uint32_t)to.y));
                     K1 = K;
-                    XL1 = (Kc + (b == 1u ? E1 : G1)) & live1; XT1 = (Kc + (b == 0u ? E0 : G0)) & live1;
+                    XL1 = (Kc + lane_select(isL, E1, G1)) & live1; XT1 = (Kc + lane_select(isT, E0, G0)) & live1;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 cje = cje_n; cjo = cjo_n; ci = ci_n;
-                te = t0[ci * kNAA1 + cje]; to = t1[ci * kNAA1 + cjo];
+                te = entry(t0, ci, cje); to = entry(t1, ci, cjo);
                 ++i;
-            }
+            };
+            for (; tau < hi; ++tau) step();  // (unrolling makes the compiler turn the selects into branches)
             // back to score / (identities << 2 | back pointer) for the closing rows (from the keys
             // alone: no comparison result is carried out of the loop)
             asm volatile("" : "+v"(K0), "+v"(K1));
