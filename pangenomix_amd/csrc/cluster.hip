@@ -14,19 +14,26 @@
 //   index   direct-address CSR over the batch's distinct (word, slot, multiplicity) entries
 //           (counting sort: histogram -> exclusive scan -> scatter)
 //   count   one workgroup per representative streams the representative's distinct-word list
-//           from HBM (coalesced), probes the CSR, and accumulates the short-word counters
-//           min(mult_q, mult_r) and the smallest shared code for all batch slots in LDS; long
-//           posting lists are walked by whole waves; pairs reaching required_aan are emitted
+//           from HBM (coalesced), probes the CSR (one 8-byte gather per word), and accumulates
+//           the short-word counters min(mult_q, mult_r) and the smallest shared code for all
+//           batch slots in LDS; long posting lists are walked by whole waves; counters are
+//           cleared and scanned four at a time, and only groups reaching the batch's smallest
+//           threshold are looked at one by one; pairs reaching required_aan are emitted
 //   diag    one wave per pair: k-mer diagonal histogram in LDS, best band window
 //   align   banded DP on the anti-diagonal wavefront: four pairs per wave (one per DPP row of
-//           16 lanes, two band columns per lane, row_shr/row_shl exchanges, int32 scores),
-//           identity carried along the best path (no traceback matrix)
+//           16 lanes, two band columns per lane, row_shr/row_shl exchanges); interior rows in
+//           "key form" (score * 4 + back-pointer code: one max3 per cell), identity carried
+//           along the best path (no traceback matrix)
 //   phase A = batch vs representatives that existed before the sweep, fully on the device;
 //             its index + table pass run one sweep ahead on a side stream
-//   phase B = members left without a representative: (1) those with no earlier unassigned
-//             candidate are certain new representatives and are confirmed at once, (2) the rest
-//             is resolved block-wise, in order, exactly; every later query is then compared
-//             only with the new representatives.
+//   phase B = members left without a representative: (1) discovery: a member none of whose
+//             earlier unassigned neighbours can reach its word threshold is a certain new
+//             representative (linear in the sweep's words: first_open / certain kernels), all
+//             confirmed at once; (2) the rest is resolved block-wise, in order, exactly; every
+//             later query is then compared only with the new representatives.
+//   A sweep makes two or three host round trips (first block, later blocks, close); their
+//   results are written to page-locked host memory by one publish kernel each, and the host's
+//   bookkeeping of a sweep runs behind the next sweep's first kernels.
 //
 // HBM layout: residues 1 byte/residue in sorted order (reverse complements appended as virtual
 // sequences); word lists (u32 code, u16 mult) at the same offsets; grow-only per-context workspace.
@@ -492,12 +499,10 @@ __global__ __launch_bounds__(1024) void select_block_kernel(const unsigned long 
 // The sweep's still-unassigned members (not final, no accepted representative): list + flags.
 __global__ __launch_bounds__(256) void list_open_kernel(const unsigned long long *__restrict__ best,
                                                        const uint8_t *__restrict__ done, uint32_t b0, uint32_t nb,
-                                                       uint32_t *__restrict__ ulist, uint8_t *__restrict__ is_open,
-                                                       uint32_t *__restrict__ n_open) {
+                                                       uint32_t *__restrict__ ulist, uint32_t *__restrict__ n_open) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nb) return;
     const bool open = !done[q] && best[q] == kNoBest;
-    is_open[q] = open;
     if (open) ulist[atomicAdd(n_open, 1u)] = b0 + q;
 }
 // Discovery of certain representatives in time linear in the sweep's words. first[code] holds,
@@ -1349,7 +1354,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_HIP(d_best_old.alloc(kBatchCap * 16));  // best keys + reverse-strand visit counters
     PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
     PGX_HIP(d_new_list.alloc(kBatchCap * 4));
-    PGX_HIP(d_flags.alloc(5 * kBatchCap));
+    PGX_HIP(d_flags.alloc(4 * kBatchCap));  // done, in-block, has-candidate, accepted
     PGX_HIP(d_list.alloc((size_t)pair_cap_k * 4));
     PGX_HIP(d_gather.alloc((size_t)pair_cap_k * sizeof(Pair)));
     PGX_HIP(d_counters.alloc(32));
@@ -1471,8 +1476,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     Pinned<Pair> h_gather;
     h_list.bind(ctx, 11); h_gather.bind(ctx, 12);
     PGX_HIP(h_list.reserve(pair_cap_k)); PGX_HIP(h_gather.reserve(pair_cap_k));
-    uint8_t *d_hascand = d_flags.as<uint8_t>() + 2 * kBatchCap, *d_accepted = d_hascand + kBatchCap,
-            *d_skip2 = d_accepted + kBatchCap;
+    uint8_t *d_hascand = d_flags.as<uint8_t>() + 2 * kBatchCap, *d_accepted = d_hascand + kBatchCap;
     uint64_t n_rounds = 0;
 
     uint64_t gpu_pairs = 0, gpu_aligned = 0, gpu_aligned_bytes = 0, table_stream_words = 0;  // actual device work (reserved stats slots)
@@ -1485,7 +1489,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         }
     };
     const bool trace = std::getenv("PGX_TRACE") != nullptr;
-    const uint32_t side_grid = std::getenv("PGX_SIDE_GRID") ? (uint32_t)atoi(std::getenv("PGX_SIDE_GRID")) : 512u;  // experiment
+    // table pass on the side stream: two workgroups per CU leave LDS and wave slots for the main
+    // stream's latency-bound kernels (256 made it twice as slow, 1024 gained 5% and cost the main path more)
+    const uint32_t side_grid = 512u;
     const auto t_loop0 = std::chrono::steady_clock::now();
     double t_resolve = 0.0, t_close = 0.0;
     uint64_t n_blocks = 0;
@@ -1654,7 +1660,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         // block is formed.
         {
             list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_blk_list.as<uint32_t>(),
-                                                               d_skip2, d_blk);  // d_blk[0] open, [1] certain: zero since the sweep began
+                                                               d_blk);  // d_blk[0] = open members: zero since the sweep began
             LAUNCH_CHECK();
             const uint32_t epoch = 1u + (uint32_t)((S.sweeps - 1) % 0xFFFFFu);
             if (epoch == 1u) PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)n_codes * 4, st));
