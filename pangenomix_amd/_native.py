@@ -22,11 +22,17 @@ class DeviceInfo(C.Structure):
                 ('clock_khz', C.c_int32), ('reserved', C.c_int32)]
 
 
+# int (*exchange)(void *user, void *dev_keys, uint32_t n_keys): in-place MIN over all processes (pgx.h)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
+
+
 class ClusterParams(C.Structure):
     _fields_ = [('alphabet', C.c_int32), ('word_len', C.c_int32), ('band_width', C.c_int32),
                 ('min_length', C.c_int32), ('both_strands', C.c_int32), ('batch_size', C.c_int32),
                 ('identity', C.c_double), ('aan_cutoff', C.c_double), ('aas_cutoff', C.c_double),
-                ('reserved', C.c_int64 * 4)]
+                # table-sharded multi-GPU mode (all zero / NULL = single GPU)
+                ('shard_index', C.c_int32), ('shard_count', C.c_int32),
+                ('exchange', EXCHANGE_FN), ('exchange_user', C.c_void_p), ('exchange_keys', C.c_void_p)]
 
 
 STAT_FIELDS = ('n_input', 'n_clustered', 'n_clusters', 'sum_len_queries', 'sum_len_reps', 'rep_words',

@@ -351,7 +351,8 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
                                                    uint32_t pair_cap,
                                                    unsigned long long *__restrict__ visits,
                                                    unsigned long long *__restrict__ rc_visits,
-                                                   uint8_t *__restrict__ mark_out, uint32_t rep_base, uint32_t tmin) {
+                                                   uint8_t *__restrict__ mark_out, uint32_t rep_base, uint32_t tmin,
+                                                   uint32_t rep_stride) {
     __shared__ __attribute__((aligned(16))) uint32_t cnt[kBatchCap];
     __shared__ __attribute__((aligned(16))) uint32_t minc[kBatchCap];
     __shared__ __attribute__((aligned(16))) uint32_t vis[NT ? kBatchCap : 4];
@@ -374,7 +375,10 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
         }
         if (threadIdx.x == 0) { wg_visits = 0ull; n_long = 0u; }
         __syncthreads();
-        const uint32_t k = table[r];
+        // TABLE: entry r is representative rep_base + r * rep_stride of the whole list (a process of
+        // the table-sharded mode streams every rep_stride-th one)
+        const uint32_t rep_index = MODE == MODE_TABLE ? rep_base + r * rep_stride : r;
+        const uint32_t k = table[rep_index];
         const uint64_t o = S.off[k];
         const uint32_t n = S.wcnt[k];
         uint32_t my_visits = 0;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
         auto finish = [&](uint32_t q) {  // counters of batch slot q -> candidate pair record
             const uint32_t c = cnt[q];
             const uint32_t ql = q >= nbq ? q - nbq : q;  // the query's local index; q >= nbq = reverse strand
-            if (NT && (MODE == MODE_TABLE || MODE == MODE_NEW) && q >= nbq && vis[q])
+            if (NT && (MODE == MODE_TABLE || MODE == MODE_NEW) && rc_visits && q >= nbq && vis[q])
                 atomicAdd(&rc_visits[ql], (unsigned long long)vis[q]);
             if (c == 0u || (int32_t)c < req_aan[b0 + ql]) return;
             if (MODE == MODE_NEW) {
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
             const uint32_t slot = atomicAdd(n_pairs, 1u);
             if (slot < pair_cap) {
                 Pair p;
-                p.q = slot_seq(S, b0, nbq, q); p.r = MODE == MODE_TABLE ? rep_base + r : k; p.cnt = c; p.minc = minc[q];
+                p.q = slot_seq(S, b0, nbq, q); p.r = MODE == MODE_TABLE ? rep_index : k; p.cnt = c; p.minc = minc[q];
                 p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
                 pairs[slot] = p;
             }
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
             for (uint32_t j = 0; j < 4; ++j) if (q4 + j < nb) finish(q4 + j);
         }
         __syncthreads();
-        if ((MODE == MODE_TABLE || MODE == MODE_NEW) && threadIdx.x == 0 && wg_visits) atomicAdd(visits, wg_visits);
+        if ((MODE == MODE_TABLE || MODE == MODE_NEW) && visits && threadIdx.x == 0 && wg_visits) atomicAdd(visits, wg_visits);
     }
 }
 
@@ -1154,6 +1158,11 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
 // ========================================================================================
 namespace {
 
+// Kernels write results straight into these buffers (publish_kernel) and read lists from them, and
+// the host polls for completion instead of making a synchronising call: the memory must be
+// COHERENT (fine-grained, never cached by the GPU), or the device could serve a re-used list from
+// its L2 and leave published records there.
+constexpr unsigned kPinnedFlags = hipHostMallocCoherent | hipHostMallocMapped;
 template <typename T>
 struct Pinned {  // page-locked host staging buffer; bound to a context slot it outlives the call
     T *p = nullptr;
@@ -1172,7 +1181,7 @@ struct Pinned {  // page-locked host staging buffer; bound to a context slot it 
                 if (a.first) (void)hipHostFree(a.first);
                 a = {nullptr, 0};
                 const size_t want = bytes + bytes / 2 + 4096;
-                hipError_t e = hipHostMalloc(&a.first, want, hipHostMallocDefault);
+                hipError_t e = hipHostMalloc(&a.first, want, kPinnedFlags);
                 if (e != hipSuccess) return e;
                 a.second = want;
             }
@@ -1183,7 +1192,7 @@ struct Pinned {  // page-locked host staging buffer; bound to a context slot it 
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = n + n / 2 + 1024;
-        return hipHostMalloc((void **)&p, cap * sizeof(T), hipHostMallocDefault);
+        return hipHostMalloc((void **)&p, cap * sizeof(T), kPinnedFlags);
     }
 };
 
@@ -1232,6 +1241,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     PGX_REQUIRE(P->identity >= 0.4 && P->identity <= 1.0, "identity must be 0.4..1.0");
     PGX_REQUIRE(P->band_width >= 1 && P->band_width <= kMaxBand, "band_width must be 1..64");
     PGX_REQUIRE(P->min_length >= P->word_len - 1, "min_length must be at least word_len - 1");
+    PGX_REQUIRE(P->shard_count >= 0 && (P->shard_count == 0 ? P->shard_index == 0 : (P->shard_index >= 0 && P->shard_index < P->shard_count)),
+                "shard_index must be in [0, shard_count)");
+    PGX_REQUIRE(P->shard_count <= 1 || P->exchange, "shard_count > 1 needs an exchange callback");
+    PGX_REQUIRE(!P->exchange || P->exchange_keys, "the exchange callback needs exchange_keys (4096 uint64 in device memory)");
     PGX_HIP(hipSetDevice(ctx->device_id));
     hipStream_t st = (hipStream_t)stream_;
     pgx_cluster_stats S{};
@@ -1457,7 +1470,18 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
     Pinned<uint32_t> h_nA;
     h_nA.bind(ctx, 10);
     PGX_HIP(h_nA.reserve(4));
-    unsigned long long *d_best = d_best_old.as<unsigned long long>(), *d_rcvis = d_best + kBatchCap;
+    unsigned long long *d_rcvis = d_best_old.as<unsigned long long>() + kBatchCap;
+    unsigned long long *d_best = P->exchange ? static_cast<unsigned long long *>(P->exchange_keys)
+                                             : d_best_old.as<unsigned long long>();
+    // table-sharded mode (see pgx.h): this process streams the representatives index % shard_count == shard_index
+    const uint32_t shard_count = P->shard_count > 0 ? (uint32_t)P->shard_count : 1u;
+    const uint32_t shard_index = P->shard_count > 0 ? (uint32_t)P->shard_index : 0u;
+    const bool count_replicated = shard_index == 0;  // work every process repeats is counted by the first one only
+    auto owned_reps = [&](uint32_t lo, uint32_t hi, uint32_t *first, uint32_t *count) {
+        *first = lo + (shard_index + shard_count - lo % shard_count) % shard_count;
+        *count = *first < hi ? (hi - *first + shard_count - 1) / shard_count : 0u;
+    };
+    uint64_t own_rep_words = 0;  // distinct words of the representatives this process streams
     Pinned<unsigned long long> h_rcvis;
     h_rcvis.bind(ctx, 9);
     PGX_HIP(h_rcvis.reserve(kBatchCap));
@@ -1501,7 +1525,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         const uint32_t nb = std::min(sweep_cap, n - b0);  // queries of this sweep
         const uint32_t ns = both ? 2 * nb : nb;           // batch slots: + one per reverse complement
         const uint32_t n_reps = (uint32_t)rep_seq.size();
-        table_stream_words += S.rep_words;  // every sweep streams the word lists of all representatives so far
+        table_stream_words += own_rep_words;  // every sweep streams the word lists of all (owned) representatives so far
         if (nt) {  // at cd-hit-est's -n 5 -c 0.8 one shared word is enough: size the pair buffers for all pairs
             const uint64_t need = (uint64_t)ns * ((uint64_t)n_reps + nb) + 1024;
             if (need > (400ull << 20)) {
@@ -1553,14 +1577,16 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 index_scatter_kernel<<<hns, 256, 0, hs>>>(DS, hb0, hns, hnb, W.bi_off, W.bi_cnt, W.bi_ent);
             }
             LAUNCH_CHECK();
-            if (n_table) {
+            uint32_t first, count;
+            owned_reps(0, n_table, &first, &count);
+            if (count) {
                 ProfScope prof(ctx, "count_kernel<table>", hs);
                 auto kern = nt ? count_kernel<MODE_TABLE, true, 256> : count_kernel<MODE_TABLE, false, 256>;
                 // on the side stream leave room (LDS, wave slots) for the main stream's small kernels
-                kern<<<std::min(n_table, hs == st ? 4096u : side_grid), 256, 0, hs>>>(
-                    DS, d_rep_seq.as<uint32_t>(), nullptr, n_table, hb0, hns, hnb, W.bi_off, W.bi_ent,
+                kern<<<std::min(count, hs == st ? 4096u : side_grid), 256, 0, hs>>>(
+                    DS, d_rep_seq.as<uint32_t>(), nullptr, count, hb0, hns, hnb, W.bi_off, W.bi_ent,
                     d_aan.as<int32_t>(), nullptr, nullptr, W.pairsA, W.nA, pair_cap,
-                    d_visits.as<unsigned long long>(), d_rcvis, nullptr, 0u, min_threshold(hb0, hnb));
+                    d_visits.as<unsigned long long>(), d_rcvis, nullptr, first, min_threshold(hb0, hnb), shard_count);
                 LAUNCH_CHECK();
             }
             return PGX_OK;
@@ -1584,13 +1610,15 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             if (rc) return rc;
             n_pre = n_reps;
         }
-        if (n_reps > n_pre) {  // representatives created after the head was enqueued (the previous sweep's)
+        uint32_t catch_first, catch_count;  // representatives created after the head was enqueued (the previous sweep's)
+        owned_reps(n_pre, n_reps, &catch_first, &catch_count);
+        if (catch_count) {
             ProfScope prof(ctx, "count_kernel<table>", st);  // a few hundred entries: latency-bound, so wide
             auto kern = nt ? count_kernel<MODE_TABLE, true, kCountWide> : count_kernel<MODE_TABLE, false, kCountWide>;
-            kern<<<std::min(n_reps - n_pre, 4096u), kCountWide, 0, st>>>(
-                DS, d_rep_seq.as<uint32_t>() + n_pre, nullptr, n_reps - n_pre, b0, ns, nb, B.bi_off, B.bi_ent,
+            kern<<<std::min(catch_count, 4096u), kCountWide, 0, st>>>(
+                DS, d_rep_seq.as<uint32_t>(), nullptr, catch_count, b0, ns, nb, B.bi_off, B.bi_ent,
                 d_aan.as<int32_t>(), nullptr, nullptr, B.pairsA, B.nA, pair_cap, d_visits.as<unsigned long long>(),
-                d_rcvis, nullptr, n_pre, tmin);
+                d_rcvis, nullptr, catch_first, tmin, shard_count);
             LAUNCH_CHECK();
         }
         // diag + align of a selection of pair records, enqueued on the stream
@@ -1621,6 +1649,14 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
             int rc = evaluate(d_rep_seq.as<uint32_t>(), B.pairsA, selA, d_best, 0u, 0);
             if (rc) return rc;
         }
+        if (P->exchange) {
+            // table-sharded mode: fold the processes' partial winners of phase A (64-bit minima)
+            PGX_HIP(spin_sync(st));
+            if (P->exchange(P->exchange_user, d_best, kBatchCap) != 0) {
+                pgx_set_error("pgx_cluster_greedy: the exchange callback failed in the sweep at %u", b0);
+                return PGX_ERR_INTERNAL;
+            }
+        }
         bool head_enqueued = !want_head;
         auto enqueue_head = [&]() -> int {
             if (head_enqueued) return PGX_OK;
@@ -1647,8 +1683,9 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 auto kern = nt ? count_kernel<MODE_NEW, true, kCountWide> : count_kernel<MODE_NEW, false, kCountWide>;
                 kern<<<d_nr ? 512u : nr, kCountWide, 0, st>>>(DS, new_list, d_nr, nr, b0, ns, nb, B.bi_off,
                                          B.bi_ent, d_aan.as<int32_t>(), d_best, d_done,
-                                         d_pairsN.as<Pair>(), d_nN, pair_cap, d_visits.as<unsigned long long>(),
-                                         d_rcvis, nullptr, 0u, tmin);
+                                         d_pairsN.as<Pair>(), d_nN, pair_cap,
+                                         count_replicated ? d_visits.as<unsigned long long>() : nullptr,
+                                         count_replicated ? d_rcvis : nullptr, nullptr, 0u, tmin, 1u);
             }
             LAUNCH_CHECK();
             const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0};
@@ -1690,7 +1727,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 kern<<<kBlockCap, kCountWide, 0, st>>>(
                     DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, B.bi_off, B.bi_ent,
                     d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis,
-                    d_hascand, 0u, tmin);
+                    d_hascand, 0u, tmin, 1u);
             }
             LAUNCH_CHECK();
             // A block member without an earlier in-block candidate (has_cand clear) is certainly a
@@ -1824,6 +1861,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                     const Pair &pr = hK.p[order_k[e]];
                     if (status[pr.r - b0] != ST_REP) continue;
                     if (pair_key(pr, true) > win) continue;
+                    if (!count_replicated) continue;
                     S.filter_pairs++;
                     if ((pr.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
                         S.aligned_pairs++;
@@ -1832,7 +1870,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                     }
                 }
             }
-            account(hK.p, nK, false);
+            if (count_replicated) account(hK.p, nK, false);
             t_resolve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count();
             // later queries against the block's new representatives (on the device)
             if (!new_reps.empty()) {
@@ -1898,6 +1936,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                 rep_seq.push_back(b0 + q);
                 S.sum_len_reps += h_len[b0 + q];
                 S.rep_words += h_wcnt[b0 + q];
+                if ((rep_seq.size() - 1) % shard_count == shard_index) own_rep_words += h_wcnt[b0 + q];
             }
         for (uint32_t q = 0; q < nb; ++q)
             if (status[q] == ST_MEMBER)
@@ -1907,14 +1946,14 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         {
             const Pair *pA = hA.p, *pN = hN.p;
             deferred = [&, b0, nA, nN, pA, pN]() -> int {
-                auto examine = [&](const Pair &p, bool is_new, uint32_t len2) {
+                auto examine = [&](const Pair &p, bool is_new, uint32_t len2, bool counted) {
                     const uint32_t k = real(p.q), q = k - b0;
                     if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) return false;
                     const unsigned long long key = pair_key(p, is_new);
                     // the one-by-one pass examines candidates in key order up to and including the winner
                     if (status[q] == ST_REP || key <= winner_key[q]) {
-                        S.filter_pairs++;
-                        if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
+                        if (counted) S.filter_pairs++;
+                        if (counted && (p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
                             S.aligned_pairs++;
                             S.aligned_rep_len += len2;
                             S.dp_cells += (uint64_t)h_len[k] * (uint64_t)(p.band_right - p.band_left + 1);
@@ -1924,10 +1963,10 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                     return true;
                 };
                 account(pA, nA, true);
-                account(pN, nN, false);
+                if (count_replicated) account(pN, nN, false);
                 bool fits = true;
-                for (uint32_t i = 0; i < nA; ++i) fits &= examine(pA[i], false, h_len[rep_seq[pA[i].r]]);
-                for (uint32_t i = 0; i < nN; ++i) fits &= examine(pN[i], true, h_len[pN[i].r]);
+                for (uint32_t i = 0; i < nA; ++i) fits &= examine(pA[i], false, h_len[rep_seq[pA[i].r]], true);
+                for (uint32_t i = 0; i < nN; ++i) fits &= examine(pN[i], true, h_len[pN[i].r], count_replicated);
                 if (!fits) {
                     pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
                     return PGX_ERR_CAPACITY;

@@ -55,3 +55,57 @@ def test_shard_bounds_cover_everything():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+
+
+# ---- clustering, table-sharded mode: the exchange callback and the result merge over gloo ----------
+def _cluster_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import torch
+    from pangenomix_amd import cluster
+    # unsigned keys as the library builds them: strand << 63 | minc << 32 | new << 31 | index; ~0 = none
+    rng = np.random.default_rng(100 + rank)
+    keys_u = rng.integers(0, 2 ** 64, size=cluster.EXCHANGE_KEYS, dtype=np.uint64)
+    keys_u[rank::7] = np.uint64(2 ** 64 - 1)                     # "no candidate on this rank"
+    keys_u[5] = np.uint64(2 ** 63 + rank)                        # top bit set on every rank
+    keys = torch.from_numpy(keys_u.view(np.int64).copy())
+    p = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
+    sp, keep = cluster.shard_params(p, rank, world, keys,
+                                    lambda t: dist.all_reduce(t, op=dist.ReduceOp.MIN))
+    assert (sp.shard_index, sp.shard_count) == (rank, world) and sp.identity == p.identity
+    rc = sp.exchange(None, None, cluster.EXCHANGE_KEYS)          # what libpgx calls once per sweep
+    assert rc == 0
+
+    def host_reduce(op):
+        def f(a):
+            t = torch.from_numpy(np.ascontiguousarray(a).astype(np.int64 if a.dtype != np.float32 else np.float32))
+            dist.all_reduce(t, op=op)
+            return t.numpy().astype(a.dtype)
+        return f
+    n = 10
+    ident = np.zeros(n, dtype=np.float32); ident[rank::world] = 0.8 + 0.01 * rank   # known to one rank each
+    strand = np.zeros(n, dtype=np.uint8); strand[rank] = 1
+    stats = {k: 10 * (rank + 1) for k in cluster.PARTIAL_STATS}
+    stats.update(n_input=n, n_clusters=3, gpu={'pairs': rank + 1, 'aligned': 1, 'aligned_bytes': 2, 'table_stream_words': 5})
+    merged = cluster.merge_shard_results((np.arange(n), np.arange(n), ident, strand, 3, stats),
+                                         host_reduce(dist.ReduceOp.SUM), host_reduce(dist.ReduceOp.MAX))
+    np.savez(os.path.join(out_dir, 'c%d.npz' % rank), before=keys_u, after=keys.numpy().view(np.uint64),
+             ident=merged[2], strand=merged[3],
+             stats=np.array([merged[5][k] for k in cluster.PARTIAL_STATS] + [merged[5]['gpu']['pairs'], merged[5]['n_input']]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_cluster_exchange_and_merge_over_gloo(world, tmp_path):
+    port = 31500 + os.getpid() % 2000 + world
+    mp.spawn(_cluster_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(str(tmp_path / ('c%d.npz' % r))) for r in range(world)]
+    want = np.minimum.reduce([o['before'] for o in outs])        # unsigned minimum
+    assert want[5] == np.uint64(2 ** 63)
+    for o in outs:
+        assert np.array_equal(o['after'], want)
+        assert np.array_equal(o['ident'], outs[0]['ident']) and (o['ident'] > 0.79).all()
+        assert o['strand'][:world].tolist() == [1] * world
+        tri = 10 * world * (world + 1) // 2
+        assert o['stats'].tolist() == [tri] * 5 + [world * (world + 1) // 2, 10]   # partial counters add, replicated stay
