@@ -51,6 +51,9 @@ def main():
     ap.add_argument('--pancore-iters', type=int, default=1000)
     ap.add_argument('--cpu-sample-genomes', type=int, default=16)
     ap.add_argument('--skip-cpu', action='store_true')
+    ap.add_argument('--shard', choices=['replicas', 'table'], default='replicas',
+                    help='N > 1: independent replicas (weak scaling, default) or ONE clustering job whose table '
+                         'pass is sharded over the ranks with a per-sweep all_reduce(MIN) over RCCL (strong scaling)')
     ap.add_argument('--only', choices=['all', 'cluster', 'pancore'], default='all',
                     help='restrict the step (used for rocprofv3 counter passes); the JSON line needs all')
     args = ap.parse_args()
@@ -67,7 +70,8 @@ def main():
         raise SystemExit('bench.py needs a GPU (there is no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or (args.shard == 'table' and 'RANK' in os.environ)   # (torchrun with one rank rehearses RCCL)
+    if use_dist:
         dist.init_process_group('nccl', device_id=dev)
     ctx = _native.Context(local_rank)
     if rank == 0:
@@ -79,7 +83,15 @@ def main():
     pset = synth.protein_set(args.workload)
     res, off, n_raw = pset.nr_arrays(progress=100 if rank == 0 else None)
     n_nr = off.size - 1
-    params = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
+    params = base_params = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
+    table_sharded = args.shard == 'table'
+    if table_sharded:   # every rank holds the same sequences; phase A of each sweep is split by representative
+        keys = torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device=dev)
+
+        def reduce_min(t):
+            if use_dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        params, _keep = cluster.shard_params(params, rank, world, keys, reduce_min)
     d_res = torch.from_numpy(res.copy()).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     S = 400
@@ -153,12 +165,25 @@ def main():
         t = torch.tensor([dt, t_cluster, t_pancore], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, t_cluster, t_pancore = (float(x) for x in t.tolist())
+    if table_sharded and use_dist and args.only != 'pancore':   # work counters and identities are partial per rank
+
+        def host_reduce(op):
+            def f(a):
+                tt = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                tt = tt.to(torch.int32) if tt.dtype == torch.uint8 else tt
+                dist.all_reduce(tt, op=op)
+                return tt.cpu().numpy().astype(a.dtype)
+            return f
+        last['cluster'] = cluster.merge_shard_results(last['cluster'], host_reduce(dist.ReduceOp.SUM),
+                                                      host_reduce(dist.ReduceOp.MAX))
 
     if args.only != 'all':
         if rank == 0:
             log('--only %s: %d step(s) done in %.3f s (no JSON line)' % (args.only, args.steps, dt))
             for k_, v in sorted(prof_all.items(), key=lambda kv: -kv[1][0]):
                 log('  %-24s %9.3f ms %6d launches' % (k_, v[0], v[1]))
+        if use_dist:
+            dist.destroy_process_group()
         ctx.close()
         return
     if rank == 0:
@@ -219,7 +244,7 @@ def main():
             sub = synth.ProteinSet(args.cpu_sample_genomes, pset.cds, pset.F, pset.C, pset.seed)
             sres, soff, _ = sub.nr_arrays()
             t1 = time.perf_counter()
-            ocl = oracle.cluster_greedy(sres, soff, params)
+            ocl = oracle.cluster_greedy(sres, soff, base_params)
             cdt = time.perf_counter() - t1
             k = 20
             t1 = time.perf_counter()
@@ -233,19 +258,22 @@ def main():
                    'pan_core': {'value': k / pdt, 'unit': 'iters/s', 'cores': 1,
                                 'sample': '%d of %d iterations, oracle/pancore_ref.c (dense incidence loop of '
                                           'pangenome_analysis.py:81-90)' % (k, n_iter)}}
+        jobs = 1 if table_sharded else world   # independent jobs running side by side
         line = {
             'metric': 'proteins/sec clustered at 0.8 identity + pan/core iters/sec, 400-genome set',
-            'value': world * n_nr * steps / t_cluster, 'unit': 'proteins/s', 'n_gpus': world, 'steps': steps,
-            'warmup': args.warmup, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'value': jobs * n_nr * steps / t_cluster, 'unit': 'proteins/s', 'n_gpus': world, 'steps': steps,
+            'warmup': args.warmup, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True,
+            'scaling': 'strong' if table_sharded else 'weak',
             'vs_baseline': None, 'dtype': 'i32', 'data': 'synthetic',
             'config': {'workload': '%s: %d genomes x %d CDS synthetic (SURVEY 8d), %d raw records -> %d '
                                    'non-redundant proteins, %d clusters at -c 0.8 -n 5; pan/core %d iterations '
                                    'on synthetic %d x %d matrix' % (args.workload, pset.n_genomes, pset.cds, n_raw,
                                                                     n_nr, n_clusters, n_iter, G, S),
-                       'parallelism': 'replicas x%d' % world},
-            'pan_core': {'value': world * n_iter * steps / t_pancore, 'unit': 'iters/s',
+                       'parallelism': ('table-sharded x%d: one job, phase A split by representative, all_reduce(MIN) of '
+                                       '4096 keys per sweep' % world) if table_sharded else 'replicas x%d' % world},
+            'pan_core': {'value': jobs * n_iter * steps / t_pancore, 'unit': 'iters/s',
                          'ms': t_pancore / steps * 1e3, 'roofline': roofline_pc},
-            'cluster': {'ms': t_cluster / steps * 1e3, 'raw_records_per_s': world * n_raw * steps / t_cluster,
+            'cluster': {'ms': t_cluster / steps * 1e3, 'raw_records_per_s': jobs * n_raw * steps / t_cluster,
                         'algorithmic_bytes': cl_bytes, 'achieved_GBs': cl_gbs, 'frac_hbm': cl_gbs / HBM_PEAK_GBS,
                         'dp_cells_per_s': st['dp_cells'] / (t_cluster / steps), 'stats': st},
             'roofline': roofline,
@@ -253,7 +281,7 @@ def main():
             'kernels_ms_per_step': {k_: {'ms': round(v[0], 4), 'launches': v[1]} for k_, v in sorted(kern.items())},
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 
