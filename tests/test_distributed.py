@@ -109,3 +109,50 @@ def test_cluster_exchange_and_merge_over_gloo(world, tmp_path):
         assert o['strand'][:world].tolist() == [1] * world
         tri = 10 * world * (world + 1) // 2
         assert o['stats'].tolist() == [tri] * 5 + [world * (world + 1) // 2, 10]   # partial counters add, replicated stay
+
+
+# ---- rank 0 drives the reference-style entry point, the other ranks serve its clustering calls -----
+def _serve_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import torch
+    import oracle
+    from pangenomix_amd import cluster
+    calls = []
+
+    def fake_cluster_sequences(residues, offsets, params, ctx=None, group=None):
+        # the oracle in place of the HIP library; one collective proves every rank takes part in the call
+        t = torch.ones(1)
+        dist.all_reduce(t, group=group)
+        calls.append((int(t.item()), int(offsets.size - 1)))
+        return oracle.cluster_greedy(residues, offsets, params)
+    cluster.cluster_sequences = fake_cluster_sequences
+    cluster.set_process_group(dist.group.WORLD)
+    fasta = os.path.join(out_dir, 'in.faa')
+    if rank == 0:
+        rng = np.random.default_rng(2)
+        aa = np.array(list('ACDEFGHIKLMNPQRSTVWY'))
+        a = ''.join(rng.choice(aa, 150))
+        with open(fasta, 'w') as f:
+            f.write('>s1 first\n%s\n>s2\n%s\n>s3\n%s\n' % (a, a[:140], ''.join(rng.choice(aa, 90))))
+        for out in ('o1', 'o2'):
+            cluster.cluster_fasta_to_clstr(fasta, os.path.join(out_dir, out), {'-n': 5, '-c': 0.8})
+        cluster.stop_workers()
+        served = -1
+    else:
+        served = cluster.serve()
+    np.save(os.path.join(out_dir, 's%d.npy' % rank), np.array([served, len(calls)] + [c[0] for c in calls]))
+    dist.destroy_process_group()
+
+
+def test_rank0_drives_and_workers_serve(tmp_path):
+    world, port = 3, 33500 + os.getpid() % 2000
+    mp.spawn(_serve_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(str(tmp_path / ('s%d.npy' % r))) for r in range(world)]
+    assert outs[0].tolist() == [-1, 2, world, world]            # rank 0 made two calls, each with all ranks in
+    for o in outs[1:]:
+        assert o.tolist() == [2, 2, world, world]               # every worker served both, then was released
+    clstr = open(str(tmp_path / 'o1.clstr')).read()
+    assert clstr.count('>Cluster') == 2 and 'at 100.00%' in clstr
+    assert open(str(tmp_path / 'o2.clstr')).read() == clstr
