@@ -49,6 +49,9 @@ def test_edge_cases(gpu_ctx):
         'ragged': [rand_seq(rng, n) for n in (11, 12, 500, 40, 41, 2000, 11)],
         'ambiguous': [s, s.replace('A', 'X').replace('C', 'B'), s.replace('L', 'J')],
         'long': [rand_seq(rng, 5000)] * 2 + [mutate(rng, rand_seq(rng, 5000), 3)],
+        # largest scores the 32-bit key form of the fast alignment path can meet (len1 + len2 = 4000, all W-W = 11)
+        'extreme scores': ['W' * 2000, 'W' * 2000, 'W' * 1999 + 'A', 'W' * 1000 + 'C' * 200 + 'W' * 799],
+        'fast path limit': [rand_seq(rng, 2001)] * 2 + [rand_seq(rng, 1999)] * 2,
     }
     p = params()
     for name, seqs in cases.items():
