@@ -1226,11 +1226,34 @@ int launch_words(pgx_ctx *ctx, hipStream_t st, const uint8_t *res, const uint64_
 
 }  // namespace
 
+static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_offsets,
+                               uint32_t n_in, uint64_t total_in, const pgx_cluster_params *P,
+                               int32_t *out_cluster, int32_t *out_member, float *out_identity,
+                               uint8_t *out_strand, uint32_t *out_n_clusters,
+                               pgx_cluster_stats *stats, void *stream_);
+
 extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_offsets,
                                       uint32_t n_in, uint64_t total_in, const pgx_cluster_params *P,
                                       int32_t *out_cluster, int32_t *out_member, float *out_identity,
                                       uint8_t *out_strand, uint32_t *out_n_clusters,
                                       pgx_cluster_stats *stats, void *stream_) {
+    const int rc = cluster_greedy_impl(ctx, d_residues, d_offsets, n_in, total_in, P, out_cluster, out_member,
+                                       out_identity, out_strand, out_n_clusters, stats, stream_);
+    if (rc != PGX_OK && ctx) {
+        // a failed call may leave kernels in flight on either stream that use the context's workspace:
+        // drain them, so that the context stays usable (the error text is the caller's to read)
+        (void)hipStreamSynchronize(static_cast<hipStream_t>(stream_));
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+
+static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_offsets,
+                               uint32_t n_in, uint64_t total_in, const pgx_cluster_params *P,
+                               int32_t *out_cluster, int32_t *out_member, float *out_identity,
+                               uint8_t *out_strand, uint32_t *out_n_clusters,
+                               pgx_cluster_stats *stats, void *stream_) {
     PGX_REQUIRE(ctx && P, "NULL argument");
     PGX_REQUIRE(n_in == 0 || (d_residues && d_offsets), "NULL sequence arrays");
     PGX_REQUIRE(out_cluster && out_member && out_identity, "NULL output arrays");

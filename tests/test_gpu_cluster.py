@@ -205,3 +205,39 @@ def test_cfg2s_full_parity_and_idempotence(gpu_ctx):
     again = gpu_ctx.cluster_greedy(rres, roff, p)
     assert again[4] == reps.size and (again[1] == 0).all()
     assert np.array_equal(again[0], np.arange(reps.size, dtype=np.int32))
+
+
+def test_errors_are_reported_and_leave_the_context_usable(gpu_ctx):
+    from pangenomix_amd._native import PgxError
+    rng = np.random.default_rng(3)
+    good = pack([rand_seq(rng, 200) for _ in range(50)])
+    p = params()
+    want = oracle.cluster_greedy(good[0], good[1], p)
+    # a sequence beyond the supported length
+    res, off = pack([rand_seq(rng, 40000), rand_seq(rng, 100)])
+    with pytest.raises(PgxError, match='exceeds the supported maximum'):
+        gpu_ctx.cluster_greedy(res, off, p)
+    assert_same(gpu_ctx.cluster_greedy(*good, p), want)
+    # parameters out of range
+    for field, value, text in (('word_len', 6, 'word_len'), ('identity', 0.2, 'identity'), ('band_width', 100, 'band_width'),
+                               ('alphabet', 3, 'alphabet')):
+        q = params()
+        setattr(q, field, value)
+        with pytest.raises(PgxError, match=text):
+            gpu_ctx.cluster_greedy(*good, q)
+    # a failing exchange callback in the table-sharded mode, in the middle of a run
+    import torch
+    from pangenomix_amd import cluster
+    res, off, _ = synth.ProteinSet(30, 500, 800, 150, 77).nr_arrays()      # several sweeps
+    keys = torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device='cuda:0')
+    calls = []
+
+    def failing(t):
+        calls.append(1)
+        if len(calls) == 2:
+            raise RuntimeError('link down')
+    sp, keep = cluster.shard_params(p, 0, 1, keys, failing)
+    with pytest.raises(PgxError, match='exchange callback failed'):
+        gpu_ctx.cluster_greedy(res, off, sp)
+    assert len(calls) == 2
+    assert_same(gpu_ctx.cluster_greedy(*good, p), want)
