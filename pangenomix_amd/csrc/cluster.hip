@@ -294,6 +294,16 @@ __global__ __launch_bounds__(256) void index_hist_kernel(DevSeqs S, uint32_t b0,
     for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&bi_cnt[S.wcode[o + i]], 1u);
 }
 
+// One bit per word code: does the code occur in the batch at all? Built from the counts in one
+// coalesced pass (0.5 MB, stays in L2); the table pass asks it before it touches the 16 MB offset
+// table, which most of a representative's words would only find empty.
+__global__ __launch_bounds__(256) void index_present_kernel(const uint32_t *__restrict__ bi_cnt, uint32_t n_codes,
+                                                           uint32_t *__restrict__ present) {
+    const uint32_t code = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long m = __ballot(code < n_codes && bi_cnt[code] != 0u);
+    if ((threadIdx.x & 31u) == 0 && code < n_codes) present[code >> 5] = (uint32_t)(m >> (threadIdx.x & 32u));
+}
+
 // Slots of a list are handed out by counting bi_cnt back down, which leaves the 16 MB count
 // table all zero again for the next sweep that uses it (no per-sweep clear).
 __global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t b0, uint32_t nb, uint32_t nbq,
@@ -344,6 +354,7 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
                                                    uint32_t ntable_host, uint32_t b0, uint32_t nb, uint32_t nbq,
                                                    const uint32_t *__restrict__ bi_off,
                                                    const uint32_t *__restrict__ bi_ent,
+                                                   const uint32_t *__restrict__ present,
                                                    const int32_t *__restrict__ req_aan,
                                                    const unsigned long long *__restrict__ best,
                                                    const uint8_t *__restrict__ qflag,
@@ -396,6 +407,7 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
             const uint32_t m = S.wmult[o + i];
             // offsets code and code + 1 in ONE 8-byte gather (dword-aligned; the pass is bound by the
             // number of random accesses, not by their bytes)
+            if (MODE == MODE_TABLE && !((present[code >> 5] >> (code & 31u)) & 1u)) continue;  // not in the batch
             const u32x2 lh = *reinterpret_cast<const u32x2_a4 *>(bi_off + code);
             const uint32_t lo = lh.x, hi = lh.y;
             if (hi - lo > kLongMin) {
@@ -1360,12 +1372,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
         d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather, d_bi_cnt2, d_bi_off2, d_bi_ent2,
-        d_pairsA2, d_scan_tmp2, d_nA2, d_pk, d_pkoff, d_first;
+        d_pairsA2, d_scan_tmp2, d_nA2, d_pk, d_pkoff, d_first, d_present, d_present2;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
                          &d_bi_cnt, &d_bi_off, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
                          &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_list, &d_gather,
-                         &d_bi_cnt2, &d_bi_off2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2, &d_pk, &d_pkoff, &d_first};
+                         &d_bi_cnt2, &d_bi_off2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2, &d_pk, &d_pkoff, &d_first, &d_present, &d_present2};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -1386,6 +1398,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));  // once: every sweep leaves it zero again
     PGX_HIP(d_bi_off.alloc(((size_t)n_codes + 1) * 4));
     PGX_HIP(d_first.alloc((size_t)n_codes * 4));
+    PGX_HIP(d_present.alloc(((size_t)n_codes / 32 + 2) * 4));
     PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
     PGX_HIP(d_best_old.alloc(kBatchCap * 16));  // best keys + reverse-strand visit counters
     PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
@@ -1415,13 +1428,14 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         PGX_HIP(d_bi_ent2.alloc((max_batch_words + 16) * 4));
         PGX_HIP(d_pairsA2.alloc((size_t)pair_cap * sizeof(Pair)));
         PGX_HIP(d_scan_tmp2.alloc(scan_bytes));
+        PGX_HIP(d_present2.alloc(((size_t)n_codes / 32 + 2) * 4));
     }
-    struct SweepBuf { uint32_t *bi_cnt, *bi_off, *bi_ent; Pair *pairsA; uint32_t *nA; void *scan_tmp; };
+    struct SweepBuf { uint32_t *bi_cnt, *bi_off, *bi_ent; Pair *pairsA; uint32_t *nA; void *scan_tmp; uint32_t *present; };
     SweepBuf sbuf[2] = {
         {d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
-         d_pairsA.as<Pair>(), d_nA2.as<uint32_t>(), d_scan_tmp.p},
+         d_pairsA.as<Pair>(), d_nA2.as<uint32_t>(), d_scan_tmp.p, d_present.as<uint32_t>()},
         {d_bi_cnt2.as<uint32_t>(), d_bi_off2.as<uint32_t>(), d_bi_ent2.as<uint32_t>(),
-         d_pairsA2.as<Pair>(), d_nA2.as<uint32_t>() + 8, d_scan_tmp2.p}};
+         d_pairsA2.as<Pair>(), d_nA2.as<uint32_t>() + 8, d_scan_tmp2.p, d_present2.as<uint32_t>()}};
 
     PGX_HIP(d_order.alloc((size_t)n * 4));
     PGX_HIP(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1590,6 +1604,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 index_hist_kernel<<<hns, 256, 0, hs>>>(DS, hb0, hns, hnb, W.bi_cnt);
             }
             LAUNCH_CHECK();
+            index_present_kernel<<<(n_codes + 255) / 256, 256, 0, hs>>>(W.bi_cnt, n_codes, W.present);
+            LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "index_scan(hipcub)", hs);
                 size_t sb = scan_bytes;
@@ -1609,7 +1625,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 // (past ~150k representatives the table pass is the longer stream of the two: it gets the machine;
                 //  measured on the 4000-genome shape, 8.2 s -> 7.6 s)
                 kern<<<std::min(count, hs == st || count > 150000u ? 4096u : side_grid), 256, 0, hs>>>(
-                    DS, d_rep_seq.as<uint32_t>(), nullptr, count, hb0, hns, hnb, W.bi_off, W.bi_ent,
+                    DS, d_rep_seq.as<uint32_t>(), nullptr, count, hb0, hns, hnb, W.bi_off, W.bi_ent, W.present,
                     d_aan.as<int32_t>(), nullptr, nullptr, W.pairsA, W.nA, pair_cap,
                     d_visits.as<unsigned long long>(), d_rcvis, nullptr, first, min_threshold(hb0, hnb), shard_count);
                 LAUNCH_CHECK();
@@ -1641,7 +1657,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             ProfScope prof(ctx, "count_kernel<table>", st);  // a few hundred entries: latency-bound, so wide
             auto kern = nt ? count_kernel<MODE_TABLE, true, kCountWide> : count_kernel<MODE_TABLE, false, kCountWide>;
             kern<<<std::min(catch_count, 4096u), kCountWide, 0, st>>>(
-                DS, d_rep_seq.as<uint32_t>(), nullptr, catch_count, b0, ns, nb, B.bi_off, B.bi_ent,
+                DS, d_rep_seq.as<uint32_t>(), nullptr, catch_count, b0, ns, nb, B.bi_off, B.bi_ent, B.present,
                 d_aan.as<int32_t>(), nullptr, nullptr, B.pairsA, B.nA, pair_cap, d_visits.as<unsigned long long>(),
                 d_rcvis, nullptr, catch_first, tmin, shard_count);
             LAUNCH_CHECK();
@@ -1707,7 +1723,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 ProfScope prof(ctx, "count_kernel<new>", st);
                 auto kern = nt ? count_kernel<MODE_NEW, true, kCountWide> : count_kernel<MODE_NEW, false, kCountWide>;
                 kern<<<d_nr ? 512u : nr, kCountWide, 0, st>>>(DS, new_list, d_nr, nr, b0, ns, nb, B.bi_off,
-                                         B.bi_ent, d_aan.as<int32_t>(), d_best, d_done,
+                                         B.bi_ent, nullptr, d_aan.as<int32_t>(), d_best, d_done,
                                          d_pairsN.as<Pair>(), d_nN, pair_cap,
                                          count_replicated ? d_visits.as<unsigned long long>() : nullptr,
                                          count_replicated ? d_rcvis : nullptr, nullptr, 0u, tmin, 1u);
@@ -1750,7 +1766,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 ProfScope prof(ctx, "count_kernel<block>", st);
                 auto kern = nt ? count_kernel<MODE_BLOCK, true, kCountWide> : count_kernel<MODE_BLOCK, false, kCountWide>;
                 kern<<<kBlockCap, kCountWide, 0, st>>>(
-                    DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, B.bi_off, B.bi_ent,
+                    DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, B.bi_off, B.bi_ent, nullptr,
                     d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis,
                     d_hascand, 0u, tmin, 1u);
             }

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def run_virtual_ranks(res, off, p, world):
     import torch
+    torch.cuda.init()
     dev = torch.device('cuda', 0)
     keys = [torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device=dev) for _ in range(world)]
     barrier = threading.Barrier(world)
