@@ -636,44 +636,95 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
     return x - v;
 }
 
-// Serial part of the diagonal test, exactly as the sequential rule states it (first best
-// window of `band_width` diagonals by complexity-weighted hits, centre = best single
-// diagonal seen while the window improved, edges trimmed). `d` packs hits | weighted<<16.
+// Band selection of the diagonal test, exactly as the sequential rule states it: the FIRST best
+// window of `band_width` diagonals by complexity-weighted hits; centre `imax` = best single
+// diagonal among those of the first window and those that entered a window at the moment it
+// became the new best (first occurrence of the largest); edges trimmed. `d` packs hits |
+// weighted << 16 per diagonal. The rule is a running scan over up to 2 L diagonals; here the
+// whole wave evaluates it: every lane slides the window over its own stretch of start positions
+// twice (once for the stretch's maximum, once -- knowing the maximum before it -- to find the
+// moments the sequential scan would have improved), with wave reductions in between. All 64
+// lanes must call; the results are valid on every lane.
 template <typename DiagPtr>
 __device__ void band_from_histogram(DiagPtr d, int len1, int len2, int band_width, int required_aa1,
                                     double cluster_thd, int *best_sum, int *bl, int *bc, int *br) {
+    const int lane = threadIdx.x & 63;
     const int nall = len1 + len2 - 1;
     const int band_b = required_aa1 - 1 >= 0 ? required_aa1 - 1 : 0;
     const int band_e = nall - band_b;
     const int band_m = band_b + band_width - 1 < band_e ? band_b + band_width - 1 : band_e;
-    int best_score = 0, best_score2 = 0, max_diag2 = 0, imax = 0;
-    for (int i = band_b; i <= band_m; ++i) {
-        const uint32_t x = d[i];
-        const int s1 = (int)(x & 0xFFFFu), s2 = (int)(x >> 16);
-        best_score += s1; best_score2 += s2;
-        if (s2 > max_diag2) { max_diag2 = s2; imax = i; }
-    }
-    int from = band_b, end = band_m, score = best_score, score2 = best_score2;
-    for (int k = from, j = band_m + 1; j < band_e; ++j, ++k) {
-        const uint32_t xk = d[k], xj = d[j];
-        score += (int)(xj & 0xFFFFu) - (int)(xk & 0xFFFFu);
-        score2 += (int)(xj >> 16) - (int)(xk >> 16);
-        if (score2 > best_score2) {
-            from = k + 1; end = j; best_score = score; best_score2 = score2;
-            if ((int)(xj >> 16) > max_diag2) { max_diag2 = (int)(xj >> 16); imax = j; }
+    const int w = band_m - band_b + 1;                         // diagonals in a window (<= 64; <= 0: none)
+    const int T = band_e - band_m - 1 > 0 && w > 0 ? band_e - band_m - 1 : 0;   // windows after the first: starts band_b + 1 .. band_b + T
+    auto hits = [&](int i) { return (int)(d[i] & 0xFFFFu); };
+    auto weighted = [&](int i) { return (int)(d[i] >> 16); };
+    auto wave_max = [&](int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; };
+    auto wave_min = [&](int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; };
+    auto wave_sum = [&](int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; };
+    // ---- first window: sums, and the first largest weighted diagonal in it (0 if all are zero) ----
+    const int x0 = lane < w ? weighted(band_b + lane) : 0;
+    const int score2_first = wave_sum(x0);
+    int max_diag2 = wave_max(x0);
+    int imax = max_diag2 > 0 ? wave_min(x0 == max_diag2 && lane < w ? band_b + lane : INT32_MAX) : 0;
+    // ---- later windows, start position band_b + t for t = 1..T: lane's stretch [t_lo, t_hi) ----
+    const int per = (T + 63) / 64;
+    const int t_lo = 1 + lane * per, t_hi = min(T + 1, t_lo + per);
+    auto window_at = [&](int t) {   // weighted sum of the window that starts at band_b + t
+        int sum = 0;
+        for (int i = 0; i < w; ++i) sum += weighted(band_b + t + i);
+        return sum;
+    };
+    int first = 0, local_max = INT32_MIN;
+    if (t_lo < t_hi) {
+        first = window_at(t_lo);
+        int sc = first;
+        local_max = sc;
+        for (int t = t_lo + 1; t < t_hi; ++t) {
+            sc += weighted(band_m + t) - weighted(band_b + t - 1);
+            local_max = max(local_max, sc);
         }
     }
+    // largest window score before this lane's stretch (the first window included)
+    int before = local_max;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(before, o);
+        if (lane >= o) before = max(before, up);
+    }
+    before = __shfl_up(before, 1);
+    before = max(lane == 0 ? INT32_MIN : before, score2_first);
+    // second slide: the moments the running scan improves (strictly), its last one, and the best
+    // diagonal entering at such a moment (first occurrence of the largest)
+    int last_t = 0, cand_val = 0, cand_t = INT32_MAX;
+    if (t_lo < t_hi) {
+        int sc = first, run = before;
+        for (int t = t_lo; t < t_hi; ++t) {
+            if (t > t_lo) sc += weighted(band_m + t) - weighted(band_b + t - 1);
+            if (sc > run) {
+                run = sc; last_t = t;
+                const int v = weighted(band_m + t);
+                if (v > cand_val) { cand_val = v; cand_t = t; }
+            }
+        }
+    }
+    const int best_t = wave_max(last_t);                         // 0 = the first window stayed the best
+    const int cand_best = wave_max(cand_val);
+    if (cand_best > max_diag2) {                                 // (a tie keeps the earlier diagonal)
+        max_diag2 = cand_best;
+        imax = band_m + wave_min(cand_val == cand_best ? cand_t : INT32_MAX);
+    }
+    int from = band_b + best_t, end = band_m + best_t;
+    int best_score = wave_sum(lane < w ? hits(from + lane) : 0);
+    // ---- trimming (at most a window's width of steps) ----
     int mlen = imax;
     if (imax > len1) mlen = nall - imax;
     const int emax = (int)((1.0 - cluster_thd) * mlen) + 1;
     // (a window without a single hit leaves imax = 0 and trims below band_b: those diagonals
     // are not stored; such a pair fails the test whatever they hold because required_aas >= 1)
     for (int j = from; j < imax; ++j) {
-        const int s1 = (int)(d[j] & 0xFFFFu);
+        const int s1 = hits(j);
         if ((imax - j) > emax || s1 < 1) { best_score -= s1; from++; } else break;
     }
     for (int j = end; j > imax; --j) {
-        const int s1 = j >= band_b ? (int)(d[j] & 0xFFFFu) : 0;
+        const int s1 = j >= band_b ? hits(j) : 0;
         if ((j - imax) > emax || s1 < 1) { best_score -= s1; end--; } else break;
     }
     *bl = from - len1 + 1; *br = end - len1 + 1; *bc = imax - len1 + 1; *best_sum = best_score;
@@ -728,7 +779,7 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
         const bool big = (uint32_t)n_d > kDiagLdsCap || (uint32_t)len1 > kDiagLdsCap;
         uint32_t *dg = big ? gscratch + (size_t)blockIdx.x * gscratch_stride : diag;
         // the query's 2-mer position lists (global scratch tail for oversized queries)
-        uint32_t *al_big = big ? dg + 2 * (kMaxLen + 1) : nullptr;
+        uint32_t *al_big = big ? dg + 2 * (gscratch_stride / 3) : nullptr;  // stride = 3 x (longest sequence, rounded up)
         for (int i = lane; i < n_d; i += 64) dg[i] = 0u;
         for (int c = lane; c < N2; c += 64) taap[c] = 0u;
         __syncthreads();
@@ -767,10 +818,12 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
             }
         }
         __syncthreads();
-        if (lane == 0) {
-            int best_sum, bl, bc, br;
+        int best_sum, bl, bc, br;
+        {
             const int bw = band_width < len1 + len2 - 2 ? band_width : len1 + len2 - 2;
             band_from_histogram(dg - d_lo, len1, len2, bw, req_aa1[k1r], cluster_thd, &best_sum, &bl, &bc, &br);
+        }
+        if (lane == 0) {
             uint32_t fl = F_EVAL;
             if (best_sum >= req_aas[k1r]) fl |= F_DIAG_PASS;
             if (!(br >= len2 || bl <= -len1 || bl > br)) fl |= F_BAND_OK;
@@ -1366,8 +1419,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         max_batch_words = std::max<uint64_t>(max_batch_words, (h_off[b1] - h_off[b0]) * (both ? 2 : 1));
     }
     const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsCap;
-    const uint32_t diag_grid = 4096, align_grid = 1024;
-    const uint32_t gs_stride = 3u * (kMaxLen + 1);
+    const uint32_t diag_grid = 8192, align_grid = 1024;  // diag: one wave per pair, ~11 workgroups fit a CU
+    const uint32_t gs_stride = 3u * ((max_len + 64u) & ~63u);  // per workgroup: 2 L diagonals + L query positions
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
         d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
