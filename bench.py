@@ -119,7 +119,8 @@ def main():
         if args.only != 'pancore':
             last['cluster'] = ctx.cluster_greedy_dev(d_res.data_ptr(), d_off.data_ptr(), n_nr, res.size, params,
                                                      stream)
-        torch.cuda.synchronize()
+        # (the call returns with its results on the host: everything it launched has completed, so
+        # the clustering time ends here; the region's closing synchronize() is in barrier())
         t1 = time.perf_counter()
         ctx.profile(True)              # three launches: the events bracket the pan/core kernels live
         ta = tb = time.perf_counter()

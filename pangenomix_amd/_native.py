@@ -4,6 +4,7 @@ missing, the first compute call raises PgxError."""
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -84,6 +85,16 @@ def lib():
     global _lib
     with _lock:
         if _lib is None:
+            # PyTorch-ROCm wheels bundle their own libamdhip64 under the same soname libpgx links to.
+            # Whichever is loaded first serves the whole process: with torch first, libpgx shares
+            # torch's runtime (streams, events and synchronize() then mean the same thing on both
+            # sides); the other order leaves torch on a runtime it was not built for, which has been
+            # seen to fail ("No HIP GPUs are available"). So torch, when installed, goes first.
+            if 'torch' not in sys.modules and os.environ.get('PGX_NO_TORCH_PRELOAD') is None:
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
             if not os.path.exists(_LIB_PATH):
                 raise PgxError('%s not found: build it with `python -c "import __graft_entry__ as g; '
                                'g.build()"` or `make -C pangenomix_amd/csrc` (there is no CPU fallback)'

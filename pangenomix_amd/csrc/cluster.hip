@@ -1302,8 +1302,12 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
                                       int32_t *out_cluster, int32_t *out_member, float *out_identity,
                                       uint8_t *out_strand, uint32_t *out_n_clusters,
                                       pgx_cluster_stats *stats, void *stream_) {
+    const auto t0 = std::chrono::steady_clock::now();
     const int rc = cluster_greedy_impl(ctx, d_residues, d_offsets, n_in, total_in, P, out_cluster, out_member,
                                        out_identity, out_strand, out_n_clusters, stats, stream_);
+    if (std::getenv("PGX_TRACE"))
+        fprintf(stderr, "[pgx] call total (incl. clean-up)    %8.2f ms\n",
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     if (rc != PGX_OK && ctx) {
         // a failed call may leave kernels in flight on either stream that use the context's workspace:
         // drain them, so that the context stays usable (the error text is the caller's to read)
@@ -1335,6 +1339,18 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_REQUIRE(!P->exchange || P->exchange_keys, "the exchange callback needs exchange_keys (4096 uint64 in device memory)");
     PGX_HIP(hipSetDevice(ctx->device_id));
     hipStream_t st = (hipStream_t)stream_;
+    const auto t_call0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) {
+        return 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+    };
+    const bool trace_phases = std::getenv("PGX_TRACE") != nullptr;
+    double t_mark = 0.0;
+    auto phase = [&](const char *what) {   // PGX_TRACE: host wall time of the phases outside the sweep loop
+        if (!trace_phases) return;
+        const double now = ms_since(t_call0);
+        fprintf(stderr, "[pgx] %-28s %8.2f ms\n", what, now - t_mark);
+        t_mark = now;
+    };
     pgx_cluster_stats S{};
     S.n_input = n_in;
     if (out_n_clusters) *out_n_clusters = 0;
@@ -1389,6 +1405,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         if (nxt > 0xFFFFFFF0ull) { pgx_set_error("pgx_cluster_greedy: too many residues for 32-bit packed offsets"); return PGX_ERR_CAPACITY; }
         h_pkoff[k + 1] = (uint32_t)nxt;
     }
+    phase("lengths + order");
     // per-query thresholds in double, exactly as the sequential rule computes them
     std::vector<int32_t> h_aa1(n), h_aas(n), h_aan(n);
     for (uint32_t k = 0; k < n; ++k) {
@@ -1434,6 +1451,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
+    phase("thresholds + offsets");
     PGX_HIP(d_res.alloc(total + 16));
     PGX_HIP(d_off.alloc(((size_t)nv + 1) * 8));
     PGX_HIP(d_len.alloc((size_t)nv * 4));
@@ -1510,6 +1528,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(hipMemcpyAsync(d_aan.p, h_aan.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     PGX_HIP(hipMemsetAsync(d_visits.p, 0, 8, st));
 
+    phase("alloc + upload + encode (enq)");
     // ---- word lists: size classes are contiguous because the order is by length ----------
     {
         const int wl = P->word_len;
@@ -1538,6 +1557,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     std::vector<uint32_t> h_wcnt(n);
     PGX_HIP(hipMemcpyAsync(h_wcnt.data(), d_wcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 
+    phase("word lists (enqueue)");
     // ---- sweeps ---------------------------------------------------------------------------
     std::vector<uint32_t> rep_seq;            // representative index -> sorted sequence index
     std::vector<int32_t> cluster_of(n, -1);   // sorted sequence index -> cluster
@@ -1606,6 +1626,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     // table pass on the side stream: two workgroups per CU leave LDS and wave slots for the main
     // stream's latency-bound kernels (256 made it twice as slow, 1024 gained 5% and cost the main path more)
     const uint32_t side_grid = 512u;
+    phase("sweep set-up");
     const auto t_loop0 = std::chrono::steady_clock::now();
     double t_resolve = 0.0, t_close = 0.0;
     uint64_t n_blocks = 0;
@@ -2099,6 +2120,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     S.reserved[3] = table_stream_words;
     S.n_clusters = rep_seq.size();
 
+    phase("sweep loop");
     // ---- outputs in the caller's order; member numbers follow the sorted order (A.3) ------
     std::vector<uint32_t> members(rep_seq.size(), 0);
     for (uint32_t k = 0; k < n; ++k) {
@@ -2109,6 +2131,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         out_identity[o] = iden_of[k] >= 0 ? (float)iden_of[k] / (float)h_len[k] : 0.f;
         if (out_strand) out_strand[o] = iden_of[k] >= 0 ? strand_of[k] : 0;
     }
+    phase("outputs");
     if (out_n_clusters) *out_n_clusters = (uint32_t)rep_seq.size();
     if (stats) *stats = S;
     return PGX_OK;
