@@ -2115,6 +2115,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     unsigned long long visits_table = 0;
     PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
+    PGX_HIP(hipStreamSynchronize(ctx->stream2));  // idle by now; lets the runtime retire the side stream's commands here
     S.posting_visits = visits_table + visits_rc;
     S.reserved[0] = gpu_pairs; S.reserved[1] = gpu_aligned; S.reserved[2] = gpu_aligned_bytes;
     S.reserved[3] = table_stream_words;
