@@ -442,9 +442,12 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
             if (c == 0u || (int32_t)c < req_aan[b0 + ql]) return;
             if (MODE == MODE_NEW) {
                 if (qflag[ql]) return;  // resolved inside a block already
+                // only candidates whose key can still beat the query's current best. The WHOLE key is
+                // compared: with the same strand and smallest shared word, a new representative found
+                // later (in a block) but standing EARLIER in the order than the current one still wins.
                 const unsigned long long bo = best[ql];
-                const unsigned long long hi = ((unsigned long long)(q >= nbq) << 63) | ((unsigned long long)minc[q] << 32);
-                if (bo != kNoBest && hi >= (bo & 0xFFFFFFFF00000000ull)) return;
+                const unsigned long long cand = ((unsigned long long)(q >= nbq) << 63) | ((unsigned long long)minc[q] << 32) | kNewBit | k;
+                if (bo != kNoBest && cand > bo) return;
             }
             if (MODE == MODE_BLOCK && !qflag[ql]) return;  // not in the current block
             if (MODE == MODE_BLOCK) mark_out[ql] = 1;        // this block member has an earlier in-block candidate
