@@ -1374,7 +1374,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         seq_len_kernel<<<(n_in + 3) / 4, 256, 0, st>>>(d_residues, d_offsets, n_in, d_in_len.as<uint32_t>());
     }
     LAUNCH_CHECK();
-    std::vector<uint32_t> in_len(n_in);
+    // (the per-sequence host arrays live in the context's scratch: no allocation, page faults or frees per call)
+    HostVec<uint32_t> in_len(ctx, 0, n_in);
+    PGX_REQUIRE(in_len.ok(), "out of host memory");
     PGX_HIP(hipMemcpyAsync(in_len.data(), d_in_len.p, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
     uint32_t max_len = 0;
@@ -1389,19 +1391,22 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         if ((int)in_len[i] > P->min_length) bucket[max_len - in_len[i] + 1]++;
     for (uint32_t l = 0; l <= max_len; ++l) bucket[l + 1] += bucket[l];
     const uint32_t n = bucket[max_len + 1];
-    std::vector<uint32_t> order(n);
+    HostVec<uint32_t> order(ctx, 1, n);
+    PGX_REQUIRE(order.ok(), "out of host memory");
     for (uint32_t i = 0; i < n_in; ++i)
         if ((int)in_len[i] > P->min_length) order[bucket[max_len - in_len[i]]++] = i;
     if (n == 0) { if (stats) *stats = S; return PGX_OK; }
 
     // sequences n .. 2n-1 are the reverse complements (nucleotides, both strands)
     const uint32_t nv = both ? 2 * n : n;
-    std::vector<uint64_t> h_off((size_t)nv + 1);
-    std::vector<uint32_t> h_len(nv);
+    HostVec<uint64_t> h_off(ctx, 2, (size_t)nv + 1);
+    HostVec<uint32_t> h_len(ctx, 3, nv);
+    PGX_REQUIRE(h_off.ok() && h_len.ok(), "out of host memory");
     h_off[0] = 0;
     for (uint32_t k = 0; k < nv; ++k) { h_len[k] = in_len[order[k < n ? k : k - n]]; h_off[k + 1] = h_off[k] + h_len[k]; }
     const uint64_t total = h_off[nv];
-    std::vector<uint32_t> h_pkoff((size_t)nv + 1);
+    HostVec<uint32_t> h_pkoff(ctx, 4, (size_t)nv + 1);
+    PGX_REQUIRE(h_pkoff.ok(), "out of host memory");
     h_pkoff[0] = 0;
     for (uint32_t k = 0; k < nv; ++k) {
         const uint64_t nxt = (uint64_t)h_pkoff[k] + (h_len[k] + 5) / 6;
@@ -1410,7 +1415,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     }
     phase("lengths + order");
     // per-query thresholds in double, exactly as the sequential rule computes them
-    std::vector<int32_t> h_aa1(n), h_aas(n), h_aan(n);
+    HostVec<int32_t> h_aa1(ctx, 5, n), h_aas(ctx, 6, n), h_aan(ctx, 7, n);
+    PGX_REQUIRE(h_aa1.ok() && h_aas.ok() && h_aan.ok(), "out of host memory");
     for (uint32_t k = 0; k < n; ++k) {
         const int len = (int)h_len[k];
         const int aa1 = (int)(P->identity * (double)len);
@@ -1557,14 +1563,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     DevSeqs DS{d_res.as<uint8_t>(), d_off.as<uint64_t>(), d_len.as<uint32_t>(),
                d_wcode.as<uint32_t>(), d_wmult.as<uint16_t>(), d_wcnt.as<uint32_t>(),
                d_pk.as<uint32_t>(), d_pkoff.as<uint32_t>(), n, nt ? 4 : kNAA1, nt ? 4 : 2, nt ? 1 : 0};
-    std::vector<uint32_t> h_wcnt(n);
+    HostVec<uint32_t> h_wcnt(ctx, 8, n);
+    PGX_REQUIRE(h_wcnt.ok(), "out of host memory");
     PGX_HIP(hipMemcpyAsync(h_wcnt.data(), d_wcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 
     phase("word lists (enqueue)");
     // ---- sweeps ---------------------------------------------------------------------------
     std::vector<uint32_t> rep_seq;            // representative index -> sorted sequence index
-    std::vector<int32_t> cluster_of(n, -1);   // sorted sequence index -> cluster
-    std::vector<int32_t> iden_of(n, -1);      // identical residues against the representative, -1 = is one
+    HostVec<int32_t> cluster_of(ctx, 9, n, -1);   // sorted sequence index -> cluster
+    HostVec<int32_t> iden_of(ctx, 10, n, -1);     // identical residues against the representative, -1 = is one
+    PGX_REQUIRE(cluster_of.ok() && iden_of.ok(), "out of host memory");
     Pinned<Pair> hA, hN, hK;
     Pinned<unsigned long long> h_best;
     Pinned<uint32_t> h_cnt, h_blk;
@@ -1601,7 +1609,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     uint64_t visits_rc = 0;
     uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + kBatchCap;
     std::vector<uint8_t> status(kBatchCap), won_new(kBatchCap);
-    std::vector<uint8_t> strand_of(n, 0);
+    HostVec<uint8_t> strand_of(ctx, 11, n, (uint8_t)0);
+    PGX_REQUIRE(strand_of.ok(), "out of host memory");
     std::vector<unsigned long long> winner_key(kBatchCap);  // strand<<63 | minc<<32 | new<<31 | index of the winner
     std::vector<uint32_t> member_of(kBatchCap), new_reps, order_k, rank_of(kBatchCap),
         bucket_k(kBlockCap + 2), fill_k(kBlockCap + 2), flight;

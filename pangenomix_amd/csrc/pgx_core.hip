@@ -139,6 +139,7 @@ void pgx_ctx_destroy(pgx_ctx *ctx) {
         if (a.first) (void)hipFree(a.first);
     for (auto &a : ctx->host_arena)
         if (a.first) (void)hipHostFree(a.first);
+    for (auto &a : ctx->host_scratch) std::free(a.first);
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);

@@ -9,6 +9,8 @@
 
 #include <string>
 #include <utility>
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 // Optional per-kernel timing (pgx_profile_*): HIP events recorded on the launch stream
@@ -33,6 +35,47 @@ struct pgx_ctx {
     std::vector<std::pair<void *, size_t>> arena;
     // grow-only page-locked host staging buffers (slot -> buffer), same idea
     std::vector<std::pair<void *, size_t>> host_arena;
+    // grow-only pageable host scratch (slot -> buffer): the per-sequence arrays of a clustering call
+    // (tens of MB) are neither allocated, faulted in nor freed again by every call
+    std::vector<std::pair<void *, size_t>> host_scratch;
+};
+
+// Array of n elements of T in the context's host scratch slot `slot` (uninitialised unless `fill` is given).
+// A view: the memory belongs to the context and outlives the call. Check ok() after construction.
+template <typename T>
+struct HostVec {
+    T *p = nullptr;
+    size_t n = 0;
+    HostVec(pgx_ctx *ctx, int slot, size_t count) { bind(ctx, slot, count); }
+    HostVec(pgx_ctx *ctx, int slot, size_t count, T fill) {
+        bind(ctx, slot, count);
+        if (p) std::fill(p, p + n, fill);
+    }
+    bool ok() const { return p != nullptr || n == 0; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *begin() { return p; }
+    T *end() { return p + n; }
+
+private:
+    void bind(pgx_ctx *ctx, int slot, size_t count) {
+        if ((int)ctx->host_scratch.size() <= slot) ctx->host_scratch.resize((size_t)slot + 1, {nullptr, 0});
+        auto &a = ctx->host_scratch[(size_t)slot];
+        const size_t bytes = count * sizeof(T) + 64;
+        if (a.second < bytes) {
+            std::free(a.first);
+            a = {nullptr, 0};
+            const size_t want = bytes + bytes / 4;
+            a.first = std::malloc(want);
+            if (a.first) a.second = want;
+        }
+        p = static_cast<T *>(a.first);
+        n = p ? count : 0;
+        if (!p && count) n = count;  // ok() reports the failure
+    }
 };
 
 // RAII bracket: records start/stop events on `stream` when profiling is enabled.
