@@ -1,6 +1,6 @@
 """Critical-path view of a rocprofv3 --kernel-trace CSV of one clustering run: per kernel, the
 time it occupies on the main stream, and the idle gaps of that stream (host round trips,
-launch latency). Usage: python tools/timeline.py <kernel_trace.csv> [main_queue_id]"""
+launch latency). Usage: python tools/timeline.py <kernel_trace.csv> [main_queue_id|auto [sweep_to_dump]]"""
 import re
 import sys
 
@@ -24,7 +24,7 @@ def main():
     # last clustering call only: from the last encode_gather_kernel on
     t0 = d[d.k == 'encode_gather_kernel'].Start_Timestamp.max()
     d = d[d.Start_Timestamp >= t0].sort_values('Start_Timestamp')
-    main_q = int(sys.argv[2]) if len(sys.argv) > 2 else d[d.k == 'encode_gather_kernel'].Queue_Id.iloc[0]
+    main_q = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != 'auto' else d[d.k == 'encode_gather_kernel'].Queue_Id.iloc[0]
     m = d[d.Queue_Id == main_q]
     s = d[d.Queue_Id != main_q]
     span = (d.End_Timestamp.max() - t0) / 1e3
