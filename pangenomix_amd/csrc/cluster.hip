@@ -1580,7 +1580,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     hA.bind(ctx, 0); hN.bind(ctx, 1); hK.bind(ctx, 2); h_best.bind(ctx, 3); h_cnt.bind(ctx, 4); h_blk.bind(ctx, 5);
     h_new.bind(ctx, 6); h_rep_stage[0].bind(ctx, 7); h_rep_stage[1].bind(ctx, 8);
     PGX_HIP(h_rep_stage[0].reserve(kBatchCap)); PGX_HIP(h_rep_stage[1].reserve(kBatchCap));
-    constexpr uint32_t kPrefix = 4096;  // pairs copied back together with the counters
+    constexpr uint32_t kPrefix = 4096;  // initial capacity (records) of the host copies of the phase-A / new-representative pairs
     PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(8)); PGX_HIP(h_blk.reserve(kBatchCap));
     PGX_HIP(h_new.reserve(kBatchCap)); PGX_HIP(hK.reserve(pair_cap_k)); PGX_HIP(hA.reserve(kPrefix)); PGX_HIP(hN.reserve(kPrefix));
     // device counters: [1] pairsN, [2] pairsK, [3] pairsN range start, [4] open members / block size,

@@ -27,7 +27,7 @@ def short(name):
     name = name.split('(')[0].replace('void ', '').strip()
     m = re.match(r'count_kernel<(\d)(, (true|false))?(, \d+)?>', name)
     if m:
-        return 'count_kernel<%s>' % ('table', 'new', 'block', 'flag')[int(m.group(1))]
+        return 'count_kernel<%s>' % ('table', 'new', 'block')[int(m.group(1))]
     return name
 
 

@@ -12,7 +12,7 @@ def short(name):
     base = m.group(1) if m else name[:40]
     m2 = re.search(r'count_kernel<(\d)', name)
     if m2:
-        base = 'count<%s>' % ('table', 'new', 'block', 'flag')[int(m2.group(1))]
+        base = 'count<%s>' % ('table', 'new', 'block')[int(m2.group(1))]
     return base
 
 
