@@ -378,7 +378,35 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
     // scanning therefore work on four counters per LDS access, and a group is only looked at one
     // by one when its largest counter reaches the batch's smallest threshold `tmin`.
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u), sent4 = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
-    for (uint32_t r = blockIdx.x; r < ntable; r += gridDim.x) {
+    // A workgroup walks many table entries, and every walk is a chain of dependent loads (entry ->
+    // offsets -> word codes -> presence bit -> posting offsets -> postings) with the waves parked in
+    // between (84 % of their cycles by the SQ counters). The chain is cut by fetching ahead: the entry
+    // after next, the next entry's offsets, and its first two word codes per thread (512 words at 256
+    // threads: a typical representative completely) are requested one step early.
+    // TABLE: entry r is representative rep_base + r * rep_stride of the whole list (a process of the
+    // table-sharded mode streams every rep_stride-th one).
+    const uint32_t G = gridDim.x;
+    auto entry_of = [&](uint32_t r) { return MODE == MODE_TABLE ? rep_base + r * rep_stride : r; };
+    uint32_t k_nx = blockIdx.x < ntable ? table[entry_of(blockIdx.x)] : 0u;
+    uint32_t k_nx2 = blockIdx.x + G < ntable ? table[entry_of(blockIdx.x + G)] : 0u;
+    uint64_t o_nx = S.off[k_nx];
+    uint32_t n_nx = S.wcnt[k_nx];
+    uint32_t code_nx[2], m_nx[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t i = threadIdx.x + t * THREADS;
+        code_nx[t] = i < n_nx ? S.wcode[o_nx + i] : 0u;
+        m_nx[t] = i < n_nx ? S.wmult[o_nx + i] : 0u;
+    }
+    for (uint32_t r = blockIdx.x; r < ntable; r += G) {
+        const uint32_t k = k_nx, n = n_nx;
+        const uint64_t o = o_nx;
+        const uint32_t code0[2] = {code_nx[0], code_nx[1]}, m0[2] = {m_nx[0], m_nx[1]};
+        k_nx = k_nx2;
+        if (r + G < ntable) {
+            o_nx = S.off[k_nx]; n_nx = S.wcnt[k_nx];
+            if (r + 2 * G < ntable) k_nx2 = table[entry_of(r + 2 * G)];
+        }
         for (uint32_t q4 = threadIdx.x * 4; q4 < kBatchCap; q4 += THREADS * 4) {
             *reinterpret_cast<uint4 *>(&cnt[q4]) = zero4;
             *reinterpret_cast<uint4 *>(&minc[q4]) = sent4;
@@ -386,12 +414,7 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
         }
         if (threadIdx.x == 0) { wg_visits = 0ull; n_long = 0u; }
         __syncthreads();
-        // TABLE: entry r is representative rep_base + r * rep_stride of the whole list (a process of
-        // the table-sharded mode streams every rep_stride-th one)
-        const uint32_t rep_index = MODE == MODE_TABLE ? rep_base + r * rep_stride : r;
-        const uint32_t k = table[rep_index];
-        const uint64_t o = S.off[k];
-        const uint32_t n = S.wcnt[k];
+        const uint32_t rep_index = entry_of(r);
         uint32_t my_visits = 0;
         auto visit = [&](uint32_t ent, uint32_t m, uint32_t code) {
             const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
@@ -402,19 +425,47 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
             if (NT && q >= nbq) atomicAdd(&vis[q], 1u);  // reverse strand: attributed to the query
             else ++my_visits;
         };
-        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-            const uint32_t code = S.wcode[o + i];
-            const uint32_t m = S.wmult[o + i];
-            // offsets code and code + 1 in ONE 8-byte gather (dword-aligned; the pass is bound by the
-            // number of random accesses, not by their bytes)
-            if (MODE == MODE_TABLE && !((present[code >> 5] >> (code & 31u)) & 1u)) continue;  // not in the batch
-            const u32x2 lh = *reinterpret_cast<const u32x2_a4 *>(bi_off + code);
-            const uint32_t lo = lh.x, hi = lh.y;
-            if (hi - lo > kLongMin) {
-                const uint32_t slot = atomicAdd(&n_long, 1u);
-                if (slot < kLongCap) { lq_lo[slot] = lo; lq_meta[slot] = ((hi - lo) << 16) | m; lq_code[slot] = code; continue; }
+        // two words per thread and step; all their loads are issued before the first use
+        for (uint32_t i = threadIdx.x; i < n; i += 2 * THREADS) {
+            uint32_t code[2], m[2];
+            bool live[2];
+            u32x2 lh[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t it = i + t * THREADS;
+                live[t] = it < n;
+                code[t] = i == threadIdx.x ? code0[t] : (live[t] ? S.wcode[o + it] : 0u);
+                m[t] = i == threadIdx.x ? m0[t] : (live[t] ? S.wmult[o + it] : 0u);
             }
-            for (uint32_t e = lo; e < hi; ++e) visit(bi_ent[e], m, code);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)   // TABLE: is the word in the batch at all? (0.5 MB bit map, L2-resident)
+                if (MODE == MODE_TABLE && live[t]) live[t] = (present[code[t] >> 5] >> (code[t] & 31u)) & 1u;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // offsets code and code + 1 in ONE 8-byte gather (dword-aligned)
+                lh[t] = *reinterpret_cast<const u32x2_a4 *>(bi_off + (live[t] ? code[t] : 0u));
+                if (!live[t]) lh[t].y = lh[t].x;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t lo = lh[t].x, hi = lh[t].y;
+                if (hi - lo > kLongMin) {
+                    const uint32_t slot = atomicAdd(&n_long, 1u);
+                    if (slot < kLongCap) {
+                        lq_lo[slot] = lo; lq_meta[slot] = ((hi - lo) << 16) | m[t]; lq_code[slot] = code[t];
+                        continue;
+                    }
+                }
+                for (uint32_t e = lo; e < hi; ++e) visit(bi_ent[e], m[t], code[t]);
+            }
+        }
+        if (r + G < ntable) {  // the next entry's offsets have arrived by now: its first word codes
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t i = threadIdx.x + t * THREADS;
+                code_nx[t] = i < n_nx ? S.wcode[o_nx + i] : 0u;
+                m_nx[t] = i < n_nx ? S.wmult[o_nx + i] : 0u;
+            }
         }
         __syncthreads();
         {
