@@ -370,8 +370,10 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
     // posting lists longer than kLongMin entries are queued and walked by whole waves with
     // coalesced loads (members of one family share most words: their lists have hundreds of entries)
     __shared__ uint32_t lq_lo[kLongCap], lq_meta[kLongCap], lq_code[kLongCap];
-    __shared__ uint32_t n_long;
-    __shared__ unsigned long long wg_visits;
+    // (n_long and wg_visits alternate between two copies: the one an entry used is consumed and reset
+    // after the entry's last barrier, while the next entry already fills the other)
+    __shared__ uint32_t n_long2[2];
+    __shared__ unsigned long long wg_visits2[2];
     const uint32_t ntable = d_ntable ? *d_ntable : ntable_host;
     // Nearly all counters an entry touches are chance hits of single words (a random word occurs
     // somewhere in the batch more often than not), far below any query's threshold. Clearing and
@@ -398,7 +400,18 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
         code_nx[t] = i < n_nx ? S.wcode[o_nx + i] : 0u;
         m_nx[t] = i < n_nx ? S.wmult[o_nx + i] : 0u;
     }
-    for (uint32_t r = blockIdx.x; r < ntable; r += G) {
+    // Counters start clean and every entry leaves them clean (the scan clears what it reads, four at
+    // a time, by the thread that owns the group in both loops), so an entry costs two barriers: after
+    // the word walk and after the scan (plus one when long lists were queued).
+    for (uint32_t q4 = threadIdx.x * 4; q4 < kBatchCap; q4 += THREADS * 4) {
+        *reinterpret_cast<uint4 *>(&cnt[q4]) = zero4;
+        *reinterpret_cast<uint4 *>(&minc[q4]) = sent4;
+        if (NT) *reinterpret_cast<uint4 *>(&vis[q4]) = zero4;
+    }
+    if (threadIdx.x < 2) { wg_visits2[threadIdx.x] = 0ull; n_long2[threadIdx.x] = 0u; }
+    __syncthreads();
+    uint32_t par = 0;
+    for (uint32_t r = blockIdx.x; r < ntable; r += G, par ^= 1u) {
         const uint32_t k = k_nx, n = n_nx;
         const uint64_t o = o_nx;
         const uint32_t code0[2] = {code_nx[0], code_nx[1]}, m0[2] = {m_nx[0], m_nx[1]};
@@ -407,13 +420,8 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
             o_nx = S.off[k_nx]; n_nx = S.wcnt[k_nx];
             if (r + 2 * G < ntable) k_nx2 = table[entry_of(r + 2 * G)];
         }
-        for (uint32_t q4 = threadIdx.x * 4; q4 < kBatchCap; q4 += THREADS * 4) {
-            *reinterpret_cast<uint4 *>(&cnt[q4]) = zero4;
-            *reinterpret_cast<uint4 *>(&minc[q4]) = sent4;
-            if (NT) *reinterpret_cast<uint4 *>(&vis[q4]) = zero4;
-        }
-        if (threadIdx.x == 0) { wg_visits = 0ull; n_long = 0u; }
-        __syncthreads();
+        uint32_t &n_long = n_long2[par];
+        unsigned long long &wg_visits = wg_visits2[par];
         const uint32_t rep_index = entry_of(r);
         uint32_t my_visits = 0;
         auto visit = [&](uint32_t ent, uint32_t m, uint32_t code) {
@@ -468,8 +476,8 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
             }
         }
         __syncthreads();
-        {
-            const uint32_t nl = n_long < kLongCap ? n_long : kLongCap;
+        const uint32_t nl = n_long < kLongCap ? n_long : kLongCap;   // (workgroup-uniform)
+        if (nl) {
             const uint32_t lane = threadIdx.x & 63u;
             for (uint32_t w = threadIdx.x >> 6; w < nl; w += THREADS / 64) {
                 const uint32_t lo = lq_lo[w], len = lq_meta[w] >> 16, m = lq_meta[w] & 0xFFFFu, code = lq_code[w];
@@ -483,8 +491,8 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
                 }
             }
         }
+        if (nl) __syncthreads();
         if (my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
-        __syncthreads();
         auto finish = [&](uint32_t q) {  // counters of batch slot q -> candidate pair record
             const uint32_t c = cnt[q];
             const uint32_t ql = q >= nbq ? q - nbq : q;  // the query's local index; q >= nbq = reverse strand
@@ -513,13 +521,21 @@ __global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_
         for (uint32_t q4 = threadIdx.x * 4; q4 < nb; q4 += THREADS * 4) {
             const uint4 c = *reinterpret_cast<const uint4 *>(&cnt[q4]);
             const uint32_t mx = max(max(c.x, c.y), max(c.z, c.w));
+            if (mx == 0u && !NT) continue;               // untouched group: nothing to emit, nothing to clear
             // (nucleotide reverse-strand visits are attributed per query: every slot is looked at)
-            if (!(NT && MODE != MODE_BLOCK) && mx < tmin) continue;
+            if ((NT && MODE != MODE_BLOCK) || mx >= tmin) {
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) if (q4 + j < nb) finish(q4 + j);
+                for (uint32_t j = 0; j < 4; ++j) if (q4 + j < nb) finish(q4 + j);
+            }
+            *reinterpret_cast<uint4 *>(&cnt[q4]) = zero4;
+            *reinterpret_cast<uint4 *>(&minc[q4]) = sent4;
+            if (NT) *reinterpret_cast<uint4 *>(&vis[q4]) = zero4;
         }
         __syncthreads();
-        if ((MODE == MODE_TABLE || MODE == MODE_NEW) && visits && threadIdx.x == 0 && wg_visits) atomicAdd(visits, wg_visits);
+        if (threadIdx.x == 0) {   // consume and reset this entry's copies; the next entry uses the other pair
+            if ((MODE == MODE_TABLE || MODE == MODE_NEW) && visits && wg_visits) atomicAdd(visits, wg_visits);
+            wg_visits = 0ull; n_long = 0u;
+        }
     }
 }
 
