@@ -88,12 +88,20 @@ int pgx_profile_read(pgx_ctx *ctx, int slot, char *name, size_t name_bytes, doub
 uint32_t pgx_bitmap_stride_words(uint32_t n_genes);
 
 /* bits[genome][word] |= 1 for every (row_of_record[k], genome_of_record[k]).
- * out_bits must hold n_genomes * stride_words words; it is zeroed first. */
+ * out_bits must hold n_genomes * stride_words words; it is zeroed first.
+ * Duplicates: the number of records whose bit was already set, i.e. repeated (row, genome)
+ * coordinates (counted on the device while the bitmap is built: the read-modify-write returns the
+ * word before the update). The reference's loop (pangenome_analysis.py:88-90) equals the OR/AND
+ * form only for a 0/1 table without duplicates, so the Python layer refuses a table with any.
+ * Host variant: out_duplicates may be NULL; a record out of range fails with PGX_ERR_INVALID.
+ * Device variant: d_counters = 2 x uint64 in device memory {duplicates, records out of range
+ * (skipped)}, zeroed first; may be NULL. */
 int pgx_presence_bitmap(pgx_ctx *ctx, const int32_t *row_of_record, const int32_t *genome_of_record,
-                        uint64_t n_records, uint32_t n_rows, uint32_t n_genomes, uint64_t *out_bits);
+                        uint64_t n_records, uint32_t n_rows, uint32_t n_genomes, uint64_t *out_bits,
+                        uint64_t *out_duplicates);
 int pgx_presence_bitmap_dev(pgx_ctx *ctx, const int32_t *d_row_of_record,
                             const int32_t *d_genome_of_record, uint64_t n_records, uint32_t n_rows,
-                            uint32_t n_genomes, uint64_t *d_out_bits, void *stream);
+                            uint32_t n_genomes, uint64_t *d_out_bits, uint64_t *d_counters, void *stream);
 
 /* For each iteration i and step j (genomes taken in the order perms[i][0..j]):
  *   out_pan[i][j]  = number of genes present in at least one of the first j+1 genomes
@@ -102,6 +110,13 @@ int pgx_presence_bitmap_dev(pgx_ctx *ctx, const int32_t *d_row_of_record,
  * the caller with the legacy numpy RNG, pangenome_analysis.py:84-85). Outputs [n_iter][n_genomes]. */
 int pgx_pan_core(pgx_ctx *ctx, const uint64_t *bits, uint32_t n_genes, uint32_t n_genomes,
                  const int32_t *perms, uint32_t n_iter, int32_t *out_pan, int32_t *out_core);
+/* The whole of estimate_pan_core_size()'s device work in one call (pangenome_analysis.py:72-98):
+ * COO coordinates of the binary gene x genome table and the permutations go up once, the bitmap
+ * is built and consumed on the device (no bitmap round trip), the two curves come back. Device
+ * buffers live in the context's workspace: repeated calls do not allocate. */
+int pgx_pan_core_coo(pgx_ctx *ctx, const int32_t *row_of_record, const int32_t *genome_of_record,
+                     uint64_t n_records, uint32_t n_genes, uint32_t n_genomes, const int32_t *perms,
+                     uint32_t n_iter, int32_t *out_pan, int32_t *out_core, uint64_t *out_duplicates);
 size_t pgx_pan_core_workspace_bytes(uint32_t n_genes, uint32_t n_genomes, uint32_t n_iter);
 int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uint32_t n_genomes,
                      const int32_t *d_perms, uint32_t n_iter, int32_t *d_out_pan,

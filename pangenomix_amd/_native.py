@@ -3,8 +3,8 @@ and error translation only. There is no CPU fallback -- if the library or a GPU 
 missing, the first compute call raises PgxError."""
 
 import ctypes as C
+import importlib.util
 import os
-import sys
 import threading
 
 import numpy as np
@@ -64,8 +64,10 @@ SIGNATURES = {
     'pgx_profile_read': (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
                                    C.POINTER(C.c_uint64)]),
     'pgx_bitmap_stride_words': (C.c_uint32, [C.c_uint32]),
-    'pgx_presence_bitmap': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
-    'pgx_presence_bitmap_dev': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P]),
+    'pgx_presence_bitmap': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
+    'pgx_presence_bitmap_dev': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    'pgx_pan_core_coo': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, _P,
+                                   C.POINTER(C.c_uint64)]),
     'pgx_pan_core': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, _P]),
     'pgx_pan_core_workspace_bytes': (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     'pgx_pan_core_dev': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, _P, _P,
@@ -80,21 +82,38 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process, whatever the import order. PyTorch-ROCm wheels bundle their own
+    libamdhip64 under the SAME soname (libamdhip64.so.7) libpgx links to, and the dynamic loader
+    binds every later user of that soname to whichever copy was mapped first. With the system copy
+    first, a later `import torch` would run on a runtime it was not built for (seen to fail with
+    "No HIP GPUs are available"). So: if no libamdhip64 is mapped yet and a torch installation
+    exists, its copy is mapped first -- by path, WITHOUT importing torch -- and libpgx, and torch
+    whenever it comes, share it. Without torch the system runtime (libpgx's RUNPATH) serves."""
+    try:
+        with open('/proc/self/maps') as f:
+            if 'libamdhip64' in f.read():
+                return
+    except OSError:
+        pass
+    if os.environ.get('PGX_HIP_RUNTIME') == 'system':
+        return
+    try:
+        spec = importlib.util.find_spec('torch')     # locates the package, does not import it
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libpgx.so once; raises PgxError if it has not been built."""
     global _lib
     with _lock:
         if _lib is None:
-            # PyTorch-ROCm wheels bundle their own libamdhip64 under the same soname libpgx links to.
-            # Whichever is loaded first serves the whole process: with torch first, libpgx shares
-            # torch's runtime (streams, events and synchronize() then mean the same thing on both
-            # sides); the other order leaves torch on a runtime it was not built for, which has been
-            # seen to fail ("No HIP GPUs are available"). So torch, when installed, goes first.
-            if 'torch' not in sys.modules and os.environ.get('PGX_NO_TORCH_PRELOAD') is None:
-                try:
-                    import torch  # noqa: F401
-                except ImportError:
-                    pass
+            _one_hip_runtime()
             if not os.path.exists(_LIB_PATH):
                 raise PgxError('%s not found: build it with `python -c "import __graft_entry__ as g; '
                                'g.build()"` or `make -C pangenomix_amd/csrc` (there is no CPU fallback)'
@@ -170,25 +189,43 @@ class Context(object):
         return out
 
     # -- device-resident variants (pointers are raw device addresses, e.g. torch data_ptr) --
-    def presence_bitmap_dev(self, d_rows, d_genomes, n_records, n_rows, n_genomes, d_bits, stream=0):
+    def presence_bitmap_dev(self, d_rows, d_genomes, n_records, n_rows, n_genomes, d_bits, stream=0, d_counters=None):
         check(lib().pgx_presence_bitmap_dev(self._h, d_rows, d_genomes, int(n_records), int(n_rows),
-                                            int(n_genomes), d_bits, stream))
+                                            int(n_genomes), d_bits, d_counters, stream))
 
     def pan_core_dev(self, d_bits, n_genes, n_genomes, d_perms, n_iter, d_pan, d_core, d_ws, ws_bytes, stream=0):
         check(lib().pgx_pan_core_dev(self._h, d_bits, int(n_genes), int(n_genomes), d_perms, int(n_iter),
                                      d_pan, d_core, d_ws, int(ws_bytes), stream))
 
     # -- K3 ----------------------------------------------------------------
-    def presence_bitmap(self, rows, genomes, n_rows, n_genomes):
+    def presence_bitmap(self, rows, genomes, n_rows, n_genomes, return_duplicates=False):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         genomes = np.ascontiguousarray(genomes, dtype=np.int32)
         if rows.shape != genomes.shape or rows.ndim != 1:
             raise ValueError('rows and genomes must be 1-D arrays of equal length')
         stride = lib().pgx_bitmap_stride_words(int(n_rows))
         bits = np.empty((int(n_genomes), stride), dtype=np.uint64)
+        dup = C.c_uint64(0)
         check(lib().pgx_presence_bitmap(self._h, _ptr(rows), _ptr(genomes), rows.size,
-                                        int(n_rows), int(n_genomes), _ptr(bits)))
-        return bits
+                                        int(n_rows), int(n_genomes), _ptr(bits), C.byref(dup)))
+        return (bits, int(dup.value)) if return_duplicates else bits
+
+    def pan_core_coo(self, rows, genomes, n_genes, n_genomes, perms):
+        """(pan, core, duplicates): bitmap built and consumed on the device in one call."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        genomes = np.ascontiguousarray(genomes, dtype=np.int32)
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        if rows.shape != genomes.shape or rows.ndim != 1:
+            raise ValueError('rows and genomes must be 1-D arrays of equal length')
+        n_iter = perms.shape[0]
+        if perms.ndim != 2 or perms.shape[1] != int(n_genomes):
+            raise ValueError('perms must be [n_iter, n_genomes]')
+        pan = np.empty((n_iter, int(n_genomes)), dtype=np.int32)
+        core = np.empty((n_iter, int(n_genomes)), dtype=np.int32)
+        dup = C.c_uint64(0)
+        check(lib().pgx_pan_core_coo(self._h, _ptr(rows), _ptr(genomes), rows.size, int(n_genes), int(n_genomes),
+                                     _ptr(perms), n_iter, _ptr(pan), _ptr(core), C.byref(dup)))
+        return pan, core, int(dup.value)
 
     def pan_core(self, bits, n_genes, perms):
         perms = np.ascontiguousarray(perms, dtype=np.int32)

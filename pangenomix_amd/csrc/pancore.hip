@@ -162,18 +162,39 @@ __global__ __launch_bounds__(256) void pan_core_reduce_kernel(const uint32_t *__
     }
 }
 
+// counters[0] += records whose bit was already set (duplicate coordinates), counters[1] += records
+// with a row or genome index out of range (never written). atomicOr returns the word before the
+// update, so a set bit there is a duplicate: the check the reference-side table needs (a 0/1 matrix
+// without duplicate coordinates) costs nothing beside the bitmap build itself.
 __global__ __launch_bounds__(256) void presence_bitmap_kernel(const int32_t *__restrict__ rows,
                                                              const int32_t *__restrict__ genomes,
                                                              uint64_t n, uint32_t n_rows,
                                                              uint32_t n_genomes, uint32_t stride,
-                                                             unsigned long long *__restrict__ bits) {
+                                                             unsigned long long *__restrict__ bits,
+                                                             unsigned long long *__restrict__ counters) {
+    uint32_t dup = 0, bad = 0;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n;
          k += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t r = (uint32_t)rows[k], g = (uint32_t)genomes[k];
-        if (r >= n_rows || g >= n_genomes) continue;  // host entry point validates; never write out of bounds
-        atomicOr(&bits[(size_t)g * stride + (r >> 6)], 1ull << (r & 63u));
+        if (r >= n_rows || g >= n_genomes) { ++bad; continue; }  // never write out of bounds
+        const unsigned long long bit = 1ull << (r & 63u);
+        dup += (atomicOr(&bits[(size_t)g * stride + (r >> 6)], bit) & bit) != 0ull;
+    }
+    if (counters) {
+        for (int d = 32; d > 0; d >>= 1) { dup += __shfl_xor(dup, d); bad += __shfl_xor(bad, d); }
+        if ((threadIdx.x & 63u) == 0) {
+            if (dup) atomicAdd(&counters[0], (unsigned long long)dup);
+            if (bad) atomicAdd(&counters[1], (unsigned long long)bad);
+        }
     }
 }
+
+// K3 device buffers of the host-pointer entry points live in the context's grow-only workspace
+// (slots after the clustering's), so repeated calls neither allocate nor free.
+enum { PC_SLOT_ROWS = 80, PC_SLOT_GENOMES, PC_SLOT_BITS, PC_SLOT_PERMS, PC_SLOT_PAN, PC_SLOT_CORE, PC_SLOT_WS, PC_SLOT_CNT };
+struct PcBuf : DevBuf {
+    PcBuf(pgx_ctx *c, int s) { ctx = c; slot = s; }
+};
 
 }  // namespace
 
@@ -192,12 +213,13 @@ size_t pgx_pan_core_workspace_bytes(uint32_t n_genes, uint32_t n_genomes, uint32
 
 int pgx_presence_bitmap_dev(pgx_ctx *ctx, const int32_t *d_rows, const int32_t *d_genomes,
                             uint64_t n_records, uint32_t n_rows, uint32_t n_genomes,
-                            uint64_t *d_out_bits, void *stream_) {
+                            uint64_t *d_out_bits, uint64_t *d_counters, void *stream_) {
     PGX_REQUIRE(ctx && d_out_bits, "NULL argument");
     PGX_REQUIRE(n_records == 0 || (d_rows && d_genomes), "NULL record arrays");
     hipStream_t stream = (hipStream_t)stream_;
     const uint32_t stride = pgx_bitmap_stride_words(n_rows);
     PGX_HIP(hipMemsetAsync(d_out_bits, 0, (size_t)n_genomes * stride * 8, stream));
+    if (d_counters) PGX_HIP(hipMemsetAsync(d_counters, 0, 16, stream));
     if (n_records == 0) return PGX_OK;
     const uint64_t want = (n_records + 255) / 256;
     const uint32_t grid = (uint32_t)(want < 4096 ? want : 4096);
@@ -205,34 +227,45 @@ int pgx_presence_bitmap_dev(pgx_ctx *ctx, const int32_t *d_rows, const int32_t *
         ProfScope prof(ctx, "presence_bitmap_kernel", stream);
         presence_bitmap_kernel<<<grid, 256, 0, stream>>>(d_rows, d_genomes, n_records, n_rows,
                                                          n_genomes, stride,
-                                                         (unsigned long long *)d_out_bits);
+                                                         (unsigned long long *)d_out_bits,
+                                                         (unsigned long long *)d_counters);
     }
     PGX_HIP(hipGetLastError());
     return PGX_OK;
 }
 
-int pgx_presence_bitmap(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, uint64_t n_records,
-                        uint32_t n_rows, uint32_t n_genomes, uint64_t *out_bits) {
-    PGX_REQUIRE(ctx && out_bits, "NULL argument");
-    PGX_REQUIRE(n_records == 0 || (rows && genomes), "NULL record arrays");
-    for (uint64_t k = 0; k < n_records; ++k)
-        PGX_REQUIRE((uint32_t)rows[k] < n_rows && (uint32_t)genomes[k] < n_genomes,
-                    "record with row or genome index out of range");
-    PGX_HIP(hipSetDevice(ctx->device_id));
+// uploads the records, builds the bitmap on the device; counters (device, 2 x u64) are left for the caller
+static int upload_and_build_bitmap(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, uint64_t n_records,
+                                   uint32_t n_rows, uint32_t n_genomes, DevBuf &d_bits, DevBuf &d_cnt) {
     const size_t nbits = (size_t)n_genomes * pgx_bitmap_stride_words(n_rows) * 8;
-    DevBuf d_rows, d_genomes, d_bits;
+    PcBuf d_rows(ctx, PC_SLOT_ROWS), d_genomes(ctx, PC_SLOT_GENOMES);
     PGX_HIP(d_rows.alloc(n_records * 4));
     PGX_HIP(d_genomes.alloc(n_records * 4));
     PGX_HIP(d_bits.alloc(nbits));
+    PGX_HIP(d_cnt.alloc(16));
     if (n_records) {
         PGX_HIP(hipMemcpyAsync(d_rows.p, rows, n_records * 4, hipMemcpyHostToDevice, ctx->stream));
         PGX_HIP(hipMemcpyAsync(d_genomes.p, genomes, n_records * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    int rc = pgx_presence_bitmap_dev(ctx, d_rows.as<int32_t>(), d_genomes.as<int32_t>(), n_records,
-                                     n_rows, n_genomes, d_bits.as<uint64_t>(), ctx->stream);
+    return pgx_presence_bitmap_dev(ctx, d_rows.as<int32_t>(), d_genomes.as<int32_t>(), n_records, n_rows,
+                                   n_genomes, d_bits.as<uint64_t>(), d_cnt.as<uint64_t>(), ctx->stream);
+}
+
+int pgx_presence_bitmap(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, uint64_t n_records,
+                        uint32_t n_rows, uint32_t n_genomes, uint64_t *out_bits, uint64_t *out_duplicates) {
+    PGX_REQUIRE(ctx && out_bits, "NULL argument");
+    PGX_REQUIRE(n_records == 0 || (rows && genomes), "NULL record arrays");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    const size_t nbits = (size_t)n_genomes * pgx_bitmap_stride_words(n_rows) * 8;
+    PcBuf d_bits(ctx, PC_SLOT_BITS), d_cnt(ctx, PC_SLOT_CNT);
+    int rc = upload_and_build_bitmap(ctx, rows, genomes, n_records, n_rows, n_genomes, d_bits, d_cnt);
     if (rc != PGX_OK) return rc;
+    uint64_t cnt[2] = {0, 0};
     if (nbits) PGX_HIP(hipMemcpyAsync(out_bits, d_bits.p, nbits, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(hipStreamSynchronize(ctx->stream));
+    PGX_REQUIRE(cnt[1] == 0, "record with row or genome index out of range");
+    if (out_duplicates) *out_duplicates = cnt[0];
     return PGX_OK;
 }
 
@@ -268,31 +301,62 @@ int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uin
     return PGX_OK;
 }
 
+// bitmap already on the device (d_bits): permutations up, curves down
+static int pan_core_from_device_bitmap(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uint32_t n_genomes,
+                                       const int32_t *perms, uint32_t n_iter, int32_t *out_pan, int32_t *out_core) {
+    for (size_t k = 0; k < (size_t)n_iter * n_genomes; ++k)
+        PGX_REQUIRE((uint32_t)perms[k] < n_genomes, "permutation entry out of range");
+    const size_t nperm = (size_t)n_iter * n_genomes * 4;
+    const size_t nws = pgx_pan_core_workspace_bytes(n_genes, n_genomes, n_iter);
+    PcBuf d_perms(ctx, PC_SLOT_PERMS), d_pan(ctx, PC_SLOT_PAN), d_core(ctx, PC_SLOT_CORE), d_ws(ctx, PC_SLOT_WS);
+    PGX_HIP(d_perms.alloc(nperm));
+    PGX_HIP(d_pan.alloc(nperm));
+    PGX_HIP(d_core.alloc(nperm));
+    PGX_HIP(d_ws.alloc(nws));
+    PGX_HIP(hipMemcpyAsync(d_perms.p, perms, nperm, hipMemcpyHostToDevice, ctx->stream));
+    int rc = pgx_pan_core_dev(ctx, d_bits, n_genes, n_genomes, d_perms.as<int32_t>(), n_iter,
+                              d_pan.as<int32_t>(), d_core.as<int32_t>(), d_ws.p, nws, ctx->stream);
+    if (rc != PGX_OK) return rc;
+    PGX_HIP(hipMemcpyAsync(out_pan, d_pan.p, nperm, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipMemcpyAsync(out_core, d_core.p, nperm, hipMemcpyDeviceToHost, ctx->stream));
+    return PGX_OK;
+}
+
 int pgx_pan_core(pgx_ctx *ctx, const uint64_t *bits, uint32_t n_genes, uint32_t n_genomes,
                  const int32_t *perms, uint32_t n_iter, int32_t *out_pan, int32_t *out_core) {
     PGX_REQUIRE(ctx, "NULL context");
     if (n_iter == 0 || n_genomes == 0) return PGX_OK;
     PGX_REQUIRE(bits && perms && out_pan && out_core, "NULL argument");
-    for (size_t k = 0; k < (size_t)n_iter * n_genomes; ++k)
-        PGX_REQUIRE((uint32_t)perms[k] < n_genomes, "permutation entry out of range");
     PGX_HIP(hipSetDevice(ctx->device_id));
     const size_t nbits = (size_t)n_genomes * pgx_bitmap_stride_words(n_genes) * 8;
-    const size_t nperm = (size_t)n_iter * n_genomes * 4;
-    const size_t nws = pgx_pan_core_workspace_bytes(n_genes, n_genomes, n_iter);
-    DevBuf d_bits, d_perms, d_pan, d_core, d_ws;
+    PcBuf d_bits(ctx, PC_SLOT_BITS);
     PGX_HIP(d_bits.alloc(nbits));
-    PGX_HIP(d_perms.alloc(nperm));
-    PGX_HIP(d_pan.alloc(nperm));
-    PGX_HIP(d_core.alloc(nperm));
-    PGX_HIP(d_ws.alloc(nws));
     PGX_HIP(hipMemcpyAsync(d_bits.p, bits, nbits, hipMemcpyHostToDevice, ctx->stream));
-    PGX_HIP(hipMemcpyAsync(d_perms.p, perms, nperm, hipMemcpyHostToDevice, ctx->stream));
-    int rc = pgx_pan_core_dev(ctx, d_bits.as<uint64_t>(), n_genes, n_genomes, d_perms.as<int32_t>(),
-                              n_iter, d_pan.as<int32_t>(), d_core.as<int32_t>(), d_ws.p, nws, ctx->stream);
+    int rc = pan_core_from_device_bitmap(ctx, d_bits.as<uint64_t>(), n_genes, n_genomes, perms, n_iter, out_pan, out_core);
     if (rc != PGX_OK) return rc;
-    PGX_HIP(hipMemcpyAsync(out_pan, d_pan.p, nperm, hipMemcpyDeviceToHost, ctx->stream));
-    PGX_HIP(hipMemcpyAsync(out_core, d_core.p, nperm, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_pan_core_coo(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, uint64_t n_records,
+                     uint32_t n_genes, uint32_t n_genomes, const int32_t *perms, uint32_t n_iter,
+                     int32_t *out_pan, int32_t *out_core, uint64_t *out_duplicates) {
+    PGX_REQUIRE(ctx, "NULL context");
+    PGX_REQUIRE(n_records == 0 || (rows && genomes), "NULL record arrays");
+    PGX_REQUIRE(n_iter == 0 || n_genomes == 0 || (perms && out_pan && out_core), "NULL argument");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    PcBuf d_bits(ctx, PC_SLOT_BITS), d_cnt(ctx, PC_SLOT_CNT);
+    int rc = upload_and_build_bitmap(ctx, rows, genomes, n_records, n_genes, n_genomes, d_bits, d_cnt);
+    if (rc != PGX_OK) return rc;
+    if (n_iter && n_genomes) {
+        rc = pan_core_from_device_bitmap(ctx, d_bits.as<uint64_t>(), n_genes, n_genomes, perms, n_iter, out_pan, out_core);
+        if (rc != PGX_OK) return rc;
+    }
+    uint64_t cnt[2] = {0, 0};
+    PGX_HIP(hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipStreamSynchronize(ctx->stream));
+    PGX_REQUIRE(cnt[1] == 0, "record with row or genome index out of range");
+    if (out_duplicates) *out_duplicates = cnt[0];
     return PGX_OK;
 }
 

@@ -132,7 +132,9 @@ int pgx_ctx_create(int device_id, pgx_ctx **out) {
 void pgx_ctx_destroy(pgx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device_id);
+    // both streams drained before anything they may still read or write is released
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream2);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &a : ctx->arena)
@@ -140,7 +142,6 @@ void pgx_ctx_destroy(pgx_ctx *ctx) {
     for (auto &a : ctx->host_arena)
         if (a.first) (void)hipHostFree(a.first);
     for (auto &a : ctx->host_scratch) std::free(a.first);
-    (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);

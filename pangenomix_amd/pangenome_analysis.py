@@ -20,21 +20,19 @@ from . import _native
 
 
 def _binary_coo(df_genes):
-    """(row, col) of the stored entries. The OR/AND restatement is exact only for a
-    0/1 matrix without duplicate coordinates, which is what
-    build_genetic_feature_tables emits; anything else is rejected rather than
-    silently computed differently from the reference."""
-    coo = df_genes.data.tocoo()
+    """(row, col) int32 of the stored entries. The OR/AND restatement is exact only for a 0/1
+    matrix without duplicate coordinates, which is what
+    build_genetic_feature_tables emits; anything else is rejected rather than silently computed
+    differently from the reference. Values are checked here; duplicate coordinates are detected
+    on the device while the bitmap is built (libpgx counts the bits that were already set)."""
+    coo = df_genes.data if df_genes.data.format == 'coo' else df_genes.data.tocoo()
     data = np.asarray(coo.data)
     if data.size and not np.all(data == 1):
         raise ValueError('estimate_pan_core_size needs a binary (0/1) gene x genome table')
-    row = np.asarray(coo.row, dtype=np.int64)
-    col = np.asarray(coo.col, dtype=np.int64)
-    if row.size:
-        flat = row * coo.shape[1] + col
-        if np.unique(flat).size != flat.size:
-            raise ValueError('estimate_pan_core_size needs a table without duplicate entries')
-    return row.astype(np.int32), col.astype(np.int32)
+    return np.asarray(coo.row, dtype=np.int32), np.asarray(coo.col, dtype=np.int32)
+
+
+_DUPLICATES = 'estimate_pan_core_size needs a table without duplicate entries'
 
 
 def draw_permutations(num_strains, num_iter):
@@ -74,7 +72,7 @@ def _pan_core_sharded(ctx, bits, num_genes, perms, group, compute=None):
     mine = np.zeros((2, width, S), dtype=np.int32)
     mine[0, :hi - lo], mine[1, :hi - lo] = pan, core
     backend = dist.get_backend(group)
-    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    dev = torch.device('cuda', ctx.device_info()['device_id']) if backend == 'nccl' else torch.device('cpu')
     t = torch.from_numpy(mine).to(dev)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t, group=group)
@@ -104,7 +102,6 @@ def estimate_pan_core_size(df_genes, num_iter, log_batch=-1, ctx=None, group=Non
     print('Converting DataFrame to matrix...')
     row, col = _binary_coo(df_genes)
     ctx = ctx or _native.default_context()
-    bits = ctx.presence_bitmap(row, col, num_genes, num_strains)
 
     print('Generating pan/core curves from shuffled strains')
     perms = draw_permutations(num_strains, num_iter)
@@ -112,12 +109,14 @@ def estimate_pan_core_size(df_genes, num_iter, log_batch=-1, ctx=None, group=Non
         for i in range(log_batch, num_iter + 1, log_batch):
             print('\tIteration', i, 'of', num_iter)
     if group is not None and num_iter > 0 and num_strains > 0:
+        bits, dup = ctx.presence_bitmap(row, col, num_genes, num_strains, return_duplicates=True)
+        if dup:
+            raise ValueError(_DUPLICATES)
         pan, core = _pan_core_sharded(ctx, bits, num_genes, perms, group)
-    elif num_iter > 0 and num_strains > 0:
-        pan, core = ctx.pan_core(bits, num_genes, perms)
-    else:
-        pan = np.zeros((num_iter, num_strains), dtype=np.int32)
-        core = np.zeros((num_iter, num_strains), dtype=np.int32)
+    else:   # one call: coordinates and permutations up, bitmap built and consumed on the device, curves down
+        pan, core, dup = ctx.pan_core_coo(row, col, num_genes, num_strains, perms)
+        if dup:
+            raise ValueError(_DUPLICATES)
 
     iter_index = ['Iter' + str(x) for x in range(1, num_iter + 1)]
     pan_cols = ['Pan' + str(x) for x in range(1, num_strains + 1)]

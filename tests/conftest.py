@@ -22,11 +22,7 @@ def golden_dir():
 def gpu_ctx():
     """One libpgx context for the whole GPU session (fails loudly if the HIP library or
     the device is missing: there is no CPU fallback to fall through to)."""
-    # torch brings its own copy of the HIP runtime; when both live in one process, the tests that
-    # use torch tensors next to libpgx are reliable only with torch's runtime initialised first
-    import torch
-    torch.cuda.init()
-    from pangenomix_amd import _native
+    from pangenomix_amd import _native     # (maps ONE HIP runtime for the process, see _native._one_hip_runtime)
     ctx = _native.Context(0)
     yield ctx
     ctx.close()

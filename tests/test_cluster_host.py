@@ -8,15 +8,17 @@ from pangenomix_amd import cluster
 
 def test_read_fasta_applies_cdhit_sequence_rules(tmp_path):
     p = tmp_path / 'x.faa'
-    p.write_text('>h1 some description\nMKV\nLLA*\n>h2\nmkvlla \n\n>h3|x\tdesc\nMK-VL\n>h4\nACD EF\n>\nAAAA\n>h6\n')
+    p.write_text('>h1 some description\nMKV\nLLA*\n>h2\nmkvlla \n\n>h3|x\tdesc\nMK-VL\n>h4\nACD EF\n>\nAAAA\n>h6\n'
+                 '>h7\nMK*VL1\n2la*\n')
     headers, res, off, records = cluster.read_fasta_for_clustering(str(p))
-    assert headers == ['h1', 'h2', 'h3|x', 'h4', '', 'h6']
+    assert headers == ['h1', 'h2', 'h3|x', 'h4', '', 'h6', 'h7']
     seqs = [bytes(res[off[i]:off[i + 1]]).decode() for i in range(len(headers))]
     assert seqs == ['MKVLLA',        # trailing '*' stripped
                     'MKVLLA',        # upper-cased, trailing blanks dropped
-                    '',              # '-' is neither letter nor space: whole sequence discarded
+                    'MKVL',          # '-' is dropped, the sequence is kept (oracle/cluster_ref.c:452-458)
                     'ACDEF',         # inner blank removed
-                    'AAAA', '']
+                    'AAAA', '',
+                    'MKVLLA']        # inner '*', digits: dropped; lower case folded
     assert records[0] == '>h1 some description\nMKV\nLLA*\n'
     assert off.dtype == np.uint64 and res.dtype == np.uint8
 
@@ -29,7 +31,9 @@ def test_params_follow_the_reference_call():
     q = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8}, 'nt')    # the .fna branch (:444)
     assert (q.alphabet, q.both_strands) == (1, 1)
     assert 0 <= q.aan_cutoff < 1e-12 and abs(q.aas_cutoff - 0.2) < 1e-12   # analytic bounds only: 1-(1-c)n, 1-(1-c)4
-    assert cluster.params_from_cdhit_args({'-c': 0.8, '-M': 0, '-T': 8}).identity == 0.8   # accepted, no effect
+    assert cluster.params_from_cdhit_args({'-c': 0.8, '-M': 0, '-T': 1}).identity == 0.8   # the unchunked rule itself
+    assert cluster.params_from_cdhit_args({'-c': 0.8}, 'nt').word_len == 10               # cd-hit-est's own default
+    assert cluster.params_from_cdhit_args({'-c': 0.8}).word_len == 5
 
 
 def test_filter_cutoffs_never_fall_below_the_analytic_bound():
@@ -44,7 +48,8 @@ def test_filter_cutoffs_never_fall_below_the_analytic_bound():
 
 
 @pytest.mark.parametrize('bad', [{'-c': 0.3}, {'-n': 6}, {'-n': 1}, {'-c': 0.8, '-l': 2}, {'-c': 0.8, '-G': 0},
-                                 {'-c': 0.8, '-d': 20}, {'-c': 0.8, '-sc': 1}])
+                                 {'-c': 0.8, '-d': 20}, {'-c': 0.8, '-sc': 1}, {'-c': 0.8, '-M': 800},
+                                 {'-c': 0.8, '-M': 16000}])
 def test_params_reject_what_is_not_implemented(bad):
     with pytest.raises(ValueError):
         cluster.params_from_cdhit_args(bad)

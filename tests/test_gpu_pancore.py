@@ -49,6 +49,9 @@ def test_matches_oracle_on_seeded_inputs(G, S, density, n_iter, gpu_ctx):
     pan, core = gpu_ctx.pan_core(bits, G, perms)
     opan, ocore = oracle.pan_core(row, col, None, G, S, perms)
     assert np.array_equal(pan, opan) and np.array_equal(core, ocore)
+    # the fused entry (coordinates up, bitmap built and consumed on the device) gives the same curves
+    pan2, core2, dup = gpu_ctx.pan_core_coo(row, col, G, S, perms)
+    assert dup == 0 and np.array_equal(pan2, opan) and np.array_equal(core2, ocore)
 
 
 def test_empty_inputs(gpu_ctx):
@@ -56,6 +59,30 @@ def test_empty_inputs(gpu_ctx):
     assert bits.shape == (3, 16) and not bits.any()
     pan, core = gpu_ctx.pan_core(bits, 10, np.array([[2, 0, 1]], dtype=np.int32))
     assert pan.tolist() == [[0, 0, 0]] and core.tolist() == [[0, 0, 0]]
+
+
+def test_duplicate_coordinates_are_counted_on_the_device_and_refused(gpu_ctx):
+    """The OR/AND form equals the reference's loop only for a 0/1 table without duplicate
+    coordinates (pangenome_analysis.py:88-90 sums duplicates to 2): the bitmap build counts the
+    bits that were already set, and the entry point refuses such a table."""
+    rng = np.random.default_rng(5)
+    G, S = 5000, 37
+    dense = rng.random((G, S)) < 0.2
+    row, col = (a.astype(np.int32) for a in np.nonzero(dense))
+    extra = rng.choice(row.size, size=123, replace=False)
+    row2, col2 = np.concatenate([row, row[extra]]), np.concatenate([col, col[extra]])
+    order = rng.permutation(row2.size)
+    bits, dup = gpu_ctx.presence_bitmap(row2[order], col2[order], G, S, return_duplicates=True)
+    assert dup == 123
+    assert np.array_equal(bits, gpu_ctx.presence_bitmap(row, col, G, S))
+    assert gpu_ctx.presence_bitmap(row, col, G, S, return_duplicates=True)[1] == 0
+    coo = scipy.sparse.coo_matrix((np.ones(row2.size, dtype=np.int64), (row2, col2)), shape=(G, S))
+    lsdf = su.LightSparseDataFrame(['g%d' % i for i in range(G)], ['s%d' % i for i in range(S)], coo)
+    with pytest.raises(ValueError, match='duplicate'):
+        pa.estimate_pan_core_size(lsdf, 2, ctx=gpu_ctx)
+    two = scipy.sparse.coo_matrix((np.full(row.size, 2, dtype=np.int64), (row, col)), shape=(G, S))
+    with pytest.raises(ValueError, match='binary'):
+        pa.estimate_pan_core_size(su.LightSparseDataFrame(lsdf.index, lsdf.columns, two), 2, ctx=gpu_ctx)
 
 
 def test_rejects_bad_arguments(gpu_ctx):
