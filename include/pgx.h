@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define PGX_VERSION 100 /* 0.1.0 */
+#define PGX_VERSION 200 /* 0.2.0 */
+#define PGX_EXCHANGE_KEYS 32768u /* keys per process and exchange = the largest window */
 
 typedef enum pgx_status {
     PGX_OK = 0,
@@ -131,7 +132,8 @@ typedef struct pgx_cluster_params {
     int32_t band_width;     /* -b, default 20 */
     int32_t min_length;     /* -l, default 10: sequences with length <= this are discarded */
     int32_t both_strands;   /* -r, nucleotide only, default 1 */
-    int32_t batch_size;     /* queries per greedy sweep; 0 = library default */
+    int32_t batch_size;     /* queries per window (greedy sweep), at most PGX_EXCHANGE_KEYS; 0 = library default
+                             * (pgx_cluster_window_cap). Any value gives the same clusters. */
     double identity;        /* -c, global identity threshold (double, as cd-hit parses it) */
     /* short-word filter cut-offs as fractions of the query length. cd-hit takes
      * max(analytic bound, naa_stat[tolerance-1][100c-40][...]/100); its table is not
@@ -139,22 +141,27 @@ typedef struct pgx_cluster_params {
      * pangenomix_amd/cluster.py:filter_cutoffs and DESIGN.md "filter table"). */
     double aan_cutoff;      /* shared word_len-mers   */
     double aas_cutoff;      /* shared 2-mers (4-mers for nucleotides) on the best band */
-    /* Table-sharded multi-GPU mode, one process per GPU, every process called with the same
-     * sequences (all 0 / NULL = single GPU; the four fields take the place of reserved[4]).
-     * In every sweep this process compares the batch only with the representatives whose
-     * index % shard_count == shard_index; `exchange` then folds the processes' partial
-     * winners, and the rest of the sweep (new representatives) is replicated, so all
-     * processes return the same clusters. Work counters and identities are partial per
-     * process: sum the counters / take the maximum of out_identity and out_strand over the
-     * processes (pangenomix_amd/cluster.py does). */
+    /* Record-sharded multi-GPU mode, one process per GPU, every process called with the same
+     * sequences (all 0 / NULL = single GPU). The sorted list is cut into windows; member i of a
+     * window belongs to process i % shard_count, which runs the short-word filter and the
+     * alignments of its members against its replica of the representative index. After every
+     * evaluation the window's best keys (one uint64 per member; the minimum over the accepted
+     * representatives) are ALL-GATHERED: the library keeps them in exchange_send, calls
+     * `exchange`, and folds the rows of exchange_recv. New representatives follow from the
+     * gathered keys by a deterministic rule every process repeats, so all replicas of the index
+     * stay identical and all processes return the same clusters. Work counters and identities are
+     * partial per process: sum the counters / take the maximum of out_identity over the processes
+     * (pangenomix_amd/cluster.py does). */
     int32_t shard_index, shard_count;
-    /* In-place element-wise minimum over all processes of n_keys unsigned 64-bit keys in device
-     * memory (torch.distributed all_reduce over RCCL in the Python host). Called once per sweep
-     * with the library's stream idle; the library continues when it returns. 0 = success. */
-    int (*exchange)(void *user, void *dev_keys, uint32_t n_keys);
+    /* All-gather of PGX_EXCHANGE_KEYS uint64 per process: exchange_send of every process p into
+     * exchange_recv[p * PGX_EXCHANGE_KEYS ...] of all. The callback ENQUEUES the collective on
+     * `stream` (the stream the library works on) and returns without waiting: e.g.
+     * torch.distributed.all_gather_into_tensor under torch.cuda.ExternalStream(stream) = RCCL over
+     * xGMI with the nccl backend. 0 = success. Called a few times per window. */
+    int (*exchange)(void *user, void *stream);
     void *exchange_user;
-    void *exchange_keys;    /* device buffer of 4096 uint64 that holds the sweep's keys (the caller's
-                             * allocation, so that its collective library can address it) */
+    void *exchange_send;    /* device, PGX_EXCHANGE_KEYS uint64 (the caller's allocation, so that */
+    void *exchange_recv;    /* device, shard_count * PGX_EXCHANGE_KEYS uint64   its collective library can address it) */
 } pgx_cluster_params;
 
 /* Instrumentation that defines the roofline denominator. All are
@@ -172,11 +179,12 @@ typedef struct pgx_cluster_stats {
     uint64_t aligned_pairs;    /* of those, pairs that passed the diagonal test and were aligned */
     uint64_t aligned_rep_len;  /* A: sum of L_rep over aligned_pairs */
     uint64_t dp_cells;         /* sum over aligned_pairs of L_query * (band_right-band_left+1) */
-    uint64_t sweeps;           /* greedy sweeps (GPU path; 0 in the oracle) */
+    uint64_t sweeps;           /* windows (GPU path; 0 in the oracle) */
     /* GPU path only, actual device work incl. speculative pairs (0 in the oracle):
      * [0] candidate pairs through the diagonal test, [1] pairs aligned, [2] residue bytes of the
-     * aligned pairs (len_query + len_rep, 1 byte per residue), [3] word-list entries streamed by the
-     * table passes (sum over sweeps of the representatives' distinct words so far) */
+     * aligned pairs (len_query + len_rep, 1 byte per residue), [3] query words walked by the filter
+     * passes (an upper bound: residues of the window per pass; each costs one bit-map probe and, for
+     * the pass over the whole index, one 64-byte line read) */
     uint64_t reserved[4];
 } pgx_cluster_stats;
 
@@ -193,6 +201,8 @@ int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const uint64_t *of
 /* Same, with the sequences already resident in HBM: d_residues / d_offsets are DEVICE
  * pointers (total_bytes = offsets[n]); the out_* arrays and stats are HOST memory. All work
  * is enqueued on `stream`; the call returns after the last sweep has been resolved. */
+/* queries per window the library will use for these parameters (env PGX_WINDOW overrides) */
+uint32_t pgx_cluster_window_cap(const pgx_cluster_params *params);
 int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_offsets, uint32_t n,
                            uint64_t total_bytes, const pgx_cluster_params *params, int32_t *out_cluster,
                            int32_t *out_member, float *out_identity, uint8_t *out_strand,

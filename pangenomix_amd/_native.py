@@ -23,17 +23,19 @@ class DeviceInfo(C.Structure):
                 ('clock_khz', C.c_int32), ('reserved', C.c_int32)]
 
 
-# int (*exchange)(void *user, void *dev_keys, uint32_t n_keys): in-place MIN over all processes (pgx.h)
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)
+# int (*exchange)(void *user, void *stream): enqueue the all-gather of the window's best keys (pgx.h)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+EXCHANGE_KEYS = 32768   # PGX_EXCHANGE_KEYS
 
 
 class ClusterParams(C.Structure):
     _fields_ = [('alphabet', C.c_int32), ('word_len', C.c_int32), ('band_width', C.c_int32),
                 ('min_length', C.c_int32), ('both_strands', C.c_int32), ('batch_size', C.c_int32),
                 ('identity', C.c_double), ('aan_cutoff', C.c_double), ('aas_cutoff', C.c_double),
-                # table-sharded multi-GPU mode (all zero / NULL = single GPU)
+                # record-sharded multi-GPU mode (all zero / NULL = single GPU)
                 ('shard_index', C.c_int32), ('shard_count', C.c_int32),
-                ('exchange', EXCHANGE_FN), ('exchange_user', C.c_void_p), ('exchange_keys', C.c_void_p)]
+                ('exchange', EXCHANGE_FN), ('exchange_user', C.c_void_p), ('exchange_send', C.c_void_p),
+                ('exchange_recv', C.c_void_p)]
 
 
 STAT_FIELDS = ('n_input', 'n_clustered', 'n_clusters', 'sum_len_queries', 'sum_len_reps', 'rep_words',
@@ -46,7 +48,7 @@ class ClusterStats(C.Structure):
     def as_dict(self):
         d = {n: int(getattr(self, n)) for n in STAT_FIELDS}
         d['gpu'] = {'pairs': int(self.reserved[0]), 'aligned': int(self.reserved[1]),
-                    'aligned_bytes': int(self.reserved[2]), 'table_stream_words': int(self.reserved[3])}
+                    'aligned_bytes': int(self.reserved[2]), 'filter_walk_words': int(self.reserved[3])}
         return d
 
 
@@ -74,6 +76,7 @@ SIGNATURES = {
                                    C.c_size_t, _P]),
     'pgx_cluster_greedy': (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(ClusterParams), _P, _P, _P, _P,
                                      C.POINTER(C.c_uint32), C.POINTER(ClusterStats)]),
+    'pgx_cluster_window_cap': (C.c_uint32, [C.POINTER(ClusterParams)]),
     'pgx_cluster_greedy_dev': (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint64, C.POINTER(ClusterParams), _P, _P,
                                          _P, _P, C.POINTER(C.c_uint32), C.POINTER(ClusterStats), _P]),
 }

@@ -1,4 +1,4 @@
-// K1: greedy incremental clustering with cd-hit's rules on gfx950.
+// K1/K2: greedy incremental clustering with cd-hit's rules on gfx950.
 //
 // Replaces the reference's shell-out `cd-hit -i nr.faa -o ... -d 0 -n 5 -c 0.8`
 // (pangenome.py:444-450). The sequential rule being reproduced (oracle/cluster_ref.c):
@@ -7,38 +7,37 @@
 // required_aas  ->  banded alignment identity >= c,  candidates ordered by
 // (smallest shared word code, representative index); otherwise q becomes a representative.
 // Acceptance A(q, r) is a pure function of the pair, so the GPU evaluates pairs in bulk
-// and only the final "first accepted in key order" selection follows the greedy order.
+// and only the final "first accepted in key order" selection follows the greedy order:
+// the winner is the 64-bit minimum of  strand << 63 | smallest shared code << 32 | r  over the
+// accepted representatives r < q (r = position in the sorted order = creation order).
 //
-// One SWEEP handles up to kBatchCap batch slots (consecutive queries; with nucleotides and both
-// strands each query takes a second slot for its reverse complement):
-//   index   direct-address CSR over the batch's distinct (word, slot, multiplicity) entries
-//           (counting sort: histogram -> exclusive scan -> scatter)
-//   count   one workgroup per representative streams the representative's distinct-word list
-//           from HBM (coalesced), probes the CSR (one 8-byte gather per word), and accumulates
-//           the short-word counters min(mult_q, mult_r) and the smallest shared code for all
-//           batch slots in LDS; long posting lists are walked by whole waves; counters are
-//           cleared and scanned four at a time, and only groups reaching the batch's smallest
-//           threshold are looked at one by one; pairs reaching required_aan are emitted
-//   diag    one wave per pair: k-mer diagonal histogram in LDS, best band window
-//   align   banded DP on the anti-diagonal wavefront: four pairs per wave (one per DPP row of
-//           16 lanes, two band columns per lane, row_shr/row_shl exchanges); interior rows in
-//           "key form" (score * 4 + back-pointer code: one max3 per cell), identity carried
-//           along the best path (no traceback matrix)
-//   phase A = batch vs representatives that existed before the sweep, fully on the device;
-//             its index + table pass run one sweep ahead on a side stream
-//   phase B = members left without a representative: (1) discovery: a member none of whose
-//             earlier unassigned neighbours can reach its word threshold is a certain new
-//             representative (linear in the sweep's words: first_open / certain kernels), all
-//             confirmed at once; (2) the rest is resolved block-wise, in order, exactly; every
-//             later query is then compared only with the new representatives.
-//   A sweep makes two or three host round trips (first block, later blocks, close); their
-//   results are written to page-locked host memory by one publish kernel each, and the host's
-//   bookkeeping of a sweep runs behind the next sweep's first kernels.
+// The word table of the sequential rule is kept on the device for the whole call as an INVERTED
+// INDEX, one 64-byte line per word code (list length + first entries; longer lists continue in a
+// pool), appended to whenever representatives are confirmed. The short-word filter is QUERY-MAJOR:
+// one wave per query walks the lines of the query's words, so a query touches exactly the posting
+// entries the sequential rule visits.
+//
+// One WINDOW handles up to 16384 consecutive queries (nucleotides, both strands: each query has a
+// second slot for its reverse complement):
+//   phase A   filter over the whole index (representatives of earlier windows) -> candidate pairs
+//             -> diag (k-mer diagonal histogram, best band) -> align (banded DP on the anti-diagonal
+//             wavefront, four pairs per wave) -> best[q] = min key of the accepted pairs
+//   discovery still-open members that cannot have an earlier open candidate (linear-time word test)
+//             are certain new representatives: appended to the index at once; the filter then visits
+//             only the entries this round added, for all later members; twice, all on the device
+//   blocks    members still open are resolved <= 512 at a time, exactly: all in-block pairs are
+//             found and evaluated, the host walks the block in order, the block's new
+//             representatives are appended and compared with the later members
+//   close     winners, new representatives and pair records go to the host in one publish launch;
+//             the host's bookkeeping of a window runs behind the next window's first kernels.
+// Record-sharded mode (one process per GPU, pgx.h): window member i belongs to process i % W, which
+// filters and aligns it against its replica of the index; the members' best keys are all-gathered
+// (RCCL, enqueued on the stream) after every evaluation; discovery, index appends and the block
+// walk are replicated and deterministic, so every replica of the index stays identical.
 //
 // HBM layout: residues 1 byte/residue in sorted order (reverse complements appended as virtual
-// sequences); word lists (u32 code, u16 mult) at the same offsets; grow-only per-context workspace.
-#include <hipcub/hipcub.hpp>
-
+// sequences) + a 5-bit packed copy for the aligner; word lists (u32 code, u16 mult) at the same
+// offsets; the index lines and pool; grow-only per-context workspace.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -54,8 +53,10 @@ namespace {
 
 using namespace pgxc;
 
-constexpr uint32_t kBatchCap = 4096;   // queries per sweep = LDS counters per workgroup
-constexpr uint32_t kBlockCap = 512;    // unassigned members resolved together inside a sweep
+constexpr uint32_t kWindowMax = 32768; // largest window (queries); first-open tags keep the member in 16 bits
+constexpr int kDiscoveryRounds = 2;    // device-only rounds before the block fallback
+constexpr uint32_t kBlockCap = 512;    // unassigned members resolved together inside a window
+
 constexpr uint32_t kMaxLen = 32767;    // longest supported sequence
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kDiagLdsCap = 2048;  // diagonals / query 2-mers kept in LDS by the diag kernel
@@ -283,319 +284,451 @@ __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restric
 }
 
 // ----------------------------------------------------------------------------------------
-// batch index: CSR by word code over the batch's distinct words
+// the word index: one 64-byte line per word code, appended to when representatives are created
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void index_hist_kernel(DevSeqs S, uint32_t b0, uint32_t nb, uint32_t nbq,
-                                                        uint32_t *__restrict__ bi_cnt) {
-    if (blockIdx.x >= nb) return;
-    const uint32_t k = slot_seq(S, b0, nbq, blockIdx.x);
-    const uint64_t o = S.off[k];
-    const uint32_t n = S.wcnt[k];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&bi_cnt[S.wcode[o + i]], 1u);
-}
+// The structure the sequential rule itself walks (its "word table": per word the representatives
+// that have it), kept for the whole call and grown in place:
+//   line[code] = { len, ovf, len_prev, epoch, pending, e[11] }   (one 64-byte line: ONE memory
+//                transaction gives a query the list's length and its first 11 entries)
+//   entry      = sorted sequence index of the representative | multi << 31   (multi: the word occurs
+//                more than once in the representative; its multiplicity is then looked up in the
+//                representative's own word list -- needed only when the query repeats the word too)
+//   overflow   = entries 11.. live in pool[ovf + 1 ..], a contiguous array of capacity pool[ovf]
+//                that is re-allocated with twice the need when it fills (bump allocation)
+//   len_prev / epoch: the list length before the latest append round `epoch`, so that a pass can
+//                visit exactly the entries that round added (new representatives of the window).
+// Entries keep no order (candidates are ordered by an explicit key).
+constexpr uint32_t kInline = 11;
+struct __attribute__((aligned(64))) IndexLine {
+    uint32_t len, ovf, len_prev, epoch, pending;
+    uint32_t e[kInline];
+};
+static_assert(sizeof(IndexLine) == 64, "one line per word code");
+constexpr uint32_t kMultiBit = 0x80000000u;
 
-// One bit per word code: does the code occur in the batch at all? Built from the counts in one
-// coalesced pass (0.5 MB, stays in L2); the table pass asks it before it touches the 16 MB offset
-// table, which most of a representative's words would only find empty.
-__global__ __launch_bounds__(256) void index_present_kernel(const uint32_t *__restrict__ bi_cnt, uint32_t n_codes,
-                                                           uint32_t *__restrict__ present) {
-    const uint32_t code = blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long m = __ballot(code < n_codes && bi_cnt[code] != 0u);
-    if ((threadIdx.x & 31u) == 0 && code < n_codes) present[code >> 5] = (uint32_t)(m >> (threadIdx.x & 32u));
-}
-
-// Slots of a list are handed out by counting bi_cnt back down, which leaves the 16 MB count
-// table all zero again for the next sweep that uses it (no per-sweep clear).
-__global__ __launch_bounds__(256) void index_scatter_kernel(DevSeqs S, uint32_t b0, uint32_t nb, uint32_t nbq,
-                                                           const uint32_t *__restrict__ bi_off,
-                                                           uint32_t *__restrict__ bi_cnt,
-                                                           uint32_t *__restrict__ bi_ent) {
-    if (blockIdx.x >= nb) return;
-    const uint32_t k = slot_seq(S, b0, nbq, blockIdx.x);
-    const uint64_t o = S.off[k];
-    const uint32_t n = S.wcnt[k];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const uint32_t code = S.wcode[o + i];
-        const uint32_t pos = bi_off[code] + atomicSub(&bi_cnt[code], 1u) - 1u;
-        bi_ent[pos] = (blockIdx.x << 16) | S.wmult[o + i];
-    }
-}
-
-// ----------------------------------------------------------------------------------------
-// count: short-word counting filter, counters for the whole batch staged in LDS
-// ----------------------------------------------------------------------------------------
-// One workgroup per table entry (a representative). Keys order candidates as the
-// sequential rule does: (smallest shared word code, representative created earlier first);
-// packed as  minc << 32 | is_new << 31 | index  so that a 64-bit min picks the winner.
-//   MODE_TABLE  table = representatives that existed before this sweep (index = rep index);
-//               every batch query is compared.
-//   MODE_NEW    table = representatives confirmed during this sweep (index = sequence index);
-//               only later queries, not yet final ones (`done`), and only candidates whose
-//               key can still beat the query's current best.
-//   MODE_BLOCK  table = the current block of still-unassigned members; only later members of
-//               the same block are compared (the block is then resolved in order on the host).
-// TABLE streams tens of thousands of representatives on the side stream (256 threads, many
-// workgroups per CU); NEW and BLOCK have a few hundred table entries and are bound by the
-// latency of one workgroup's walk, so they run 1024 threads wide (kCountWide).
-enum { MODE_TABLE = 0, MODE_NEW = 1, MODE_BLOCK = 2 };
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
-constexpr unsigned long long kNoBest = ~0ull;
-constexpr uint32_t kNewBit = 0x80000000u;
-constexpr uint32_t kLongMin = 16, kLongCap = 512;  // posting lists walked wave-cooperatively
-constexpr int kCountWide = 1024;
-
-// NT adds per-query visit counters for the reverse-strand slots: the one-by-one pass only walks
-// a query's reverse-complement words when its forward strand found no representative, so
-// those visits are attributed per query (rc_visits) and summed on the host for such queries.
-template <int MODE, bool NT, int THREADS>
-__global__ __launch_bounds__(THREADS) void count_kernel(DevSeqs S, const uint32_t *__restrict__ table,
-                                                   const uint32_t *__restrict__ d_ntable,
-                                                   uint32_t ntable_host, uint32_t b0, uint32_t nb, uint32_t nbq,
-                                                   const uint32_t *__restrict__ bi_off,
-                                                   const uint32_t *__restrict__ bi_ent,
-                                                   const uint32_t *__restrict__ present,
-                                                   const int32_t *__restrict__ req_aan,
-                                                   const unsigned long long *__restrict__ best,
-                                                   const uint8_t *__restrict__ qflag,
-                                                   Pair *__restrict__ pairs, uint32_t *__restrict__ n_pairs,
-                                                   uint32_t pair_cap,
-                                                   unsigned long long *__restrict__ visits,
-                                                   unsigned long long *__restrict__ rc_visits,
-                                                   uint8_t *__restrict__ mark_out, uint32_t rep_base, uint32_t tmin,
-                                                   uint32_t rep_stride) {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[kBatchCap];
-    __shared__ __attribute__((aligned(16))) uint32_t minc[kBatchCap];
-    __shared__ __attribute__((aligned(16))) uint32_t vis[NT ? kBatchCap : 4];
-    // posting lists longer than kLongMin entries are queued and walked by whole waves with
-    // coalesced loads (members of one family share most words: their lists have hundreds of entries)
-    __shared__ uint32_t lq_lo[kLongCap], lq_meta[kLongCap], lq_code[kLongCap];
-    // (n_long and wg_visits alternate between two copies: the one an entry used is consumed and reset
-    // after the entry's last barrier, while the next entry already fills the other)
-    __shared__ uint32_t n_long2[2];
-    __shared__ unsigned long long wg_visits2[2];
-    const uint32_t ntable = d_ntable ? *d_ntable : ntable_host;
-    // Nearly all counters an entry touches are chance hits of single words (a random word occurs
-    // somewhere in the batch more often than not), far below any query's threshold. Clearing and
-    // scanning therefore work on four counters per LDS access, and a group is only looked at one
-    // by one when its largest counter reaches the batch's smallest threshold `tmin`.
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u), sent4 = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
-    // A workgroup walks many table entries, and every walk is a chain of dependent loads (entry ->
-    // offsets -> word codes -> presence bit -> posting offsets -> postings) with the waves parked in
-    // between (84 % of their cycles by the SQ counters). The chain is cut by fetching ahead: the entry
-    // after next, the next entry's offsets, and its first two word codes per thread (512 words at 256
-    // threads: a typical representative completely) are requested one step early.
-    // TABLE: entry r is representative rep_base + r * rep_stride of the whole list (a process of the
-    // table-sharded mode streams every rep_stride-th one).
-    const uint32_t G = gridDim.x;
-    auto entry_of = [&](uint32_t r) { return MODE == MODE_TABLE ? rep_base + r * rep_stride : r; };
-    uint32_t k_nx = blockIdx.x < ntable ? table[entry_of(blockIdx.x)] : 0u;
-    uint32_t k_nx2 = blockIdx.x + G < ntable ? table[entry_of(blockIdx.x + G)] : 0u;
-    uint64_t o_nx = S.off[k_nx];
-    uint32_t n_nx = S.wcnt[k_nx];
-    uint32_t code_nx[2], m_nx[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const uint32_t i = threadIdx.x + t * THREADS;
-        code_nx[t] = i < n_nx ? S.wcode[o_nx + i] : 0u;
-        m_nx[t] = i < n_nx ? S.wmult[o_nx + i] : 0u;
-    }
-    // Counters start clean and every entry leaves them clean (the scan clears what it reads, four at
-    // a time, by the thread that owns the group in both loops), so an entry costs two barriers: after
-    // the word walk and after the scan (plus one when long lists were queued).
-    for (uint32_t q4 = threadIdx.x * 4; q4 < kBatchCap; q4 += THREADS * 4) {
-        *reinterpret_cast<uint4 *>(&cnt[q4]) = zero4;
-        *reinterpret_cast<uint4 *>(&minc[q4]) = sent4;
-        if (NT) *reinterpret_cast<uint4 *>(&vis[q4]) = zero4;
-    }
-    if (threadIdx.x < 2) { wg_visits2[threadIdx.x] = 0ull; n_long2[threadIdx.x] = 0u; }
-    __syncthreads();
-    uint32_t par = 0;
-    for (uint32_t r = blockIdx.x; r < ntable; r += G, par ^= 1u) {
-        const uint32_t k = k_nx, n = n_nx;
-        const uint64_t o = o_nx;
-        const uint32_t code0[2] = {code_nx[0], code_nx[1]}, m0[2] = {m_nx[0], m_nx[1]};
-        k_nx = k_nx2;
-        if (r + G < ntable) {
-            o_nx = S.off[k_nx]; n_nx = S.wcnt[k_nx];
-            if (r + 2 * G < ntable) k_nx2 = table[entry_of(r + 2 * G)];
+// Appending the representatives list[*d_lo .. *d_hi): three passes over their word lists.
+// (1) count the new entries per code, remembering the codes touched for the first time
+__global__ __launch_bounds__(256) void index_count_kernel(DevSeqs S, const uint32_t *__restrict__ list,
+                                                         const uint32_t *__restrict__ d_lo,
+                                                         const uint32_t *__restrict__ d_hi,
+                                                         IndexLine *__restrict__ lines,
+                                                         uint32_t *__restrict__ touched,
+                                                         uint32_t *__restrict__ n_touched, uint32_t touched_cap,
+                                                         uint32_t *__restrict__ err) {
+    const uint32_t lane = threadIdx.x & 63u, lo = *d_lo, hi = *d_hi;
+    for (uint32_t w = lo + blockIdx.x * 4 + (threadIdx.x >> 6); w < hi; w += gridDim.x * 4) {
+        const uint32_t k = list[w];
+        const uint64_t o = S.off[k];
+        const uint32_t nw = S.wcnt[k];
+        for (uint32_t i = lane; i < nw; i += 64) {
+            const uint32_t code = S.wcode[o + i];
+            if (atomicAdd(&lines[code].pending, 1u) == 0u) {
+                const uint32_t t = atomicAdd(n_touched, 1u);
+                if (t < touched_cap) touched[t] = code; else *err = 1u;
+            }
         }
-        uint32_t &n_long = n_long2[par];
-        unsigned long long &wg_visits = wg_visits2[par];
-        const uint32_t rep_index = entry_of(r);
-        uint32_t my_visits = 0;
-        auto visit = [&](uint32_t ent, uint32_t m, uint32_t code) {
-            const uint32_t q = ent >> 16, mq = ent & 0xFFFFu;
-            if (MODE != MODE_TABLE && b0 + (q >= nbq ? q - nbq : q) <= k) return;  // only queries after the representative
-            atomicAdd(&cnt[q], m < mq ? m : mq);
-            atomicMin(&minc[q], code);
-            if (MODE == MODE_BLOCK) return;  // visits are counted by the TABLE / NEW passes
-            if (NT && q >= nbq) atomicAdd(&vis[q], 1u);  // reverse strand: attributed to the query
-            else ++my_visits;
-        };
-        // two words per thread and step; all their loads are issued before the first use
-        for (uint32_t i = threadIdx.x; i < n; i += 2 * THREADS) {
-            uint32_t code[2], m[2];
-            bool live[2];
-            u32x2 lh[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint32_t it = i + t * THREADS;
-                live[t] = it < n;
-                code[t] = i == threadIdx.x ? code0[t] : (live[t] ? S.wcode[o + it] : 0u);
-                m[t] = i == threadIdx.x ? m0[t] : (live[t] ? S.wmult[o + it] : 0u);
+    }
+}
+// (2) per touched code: open the round (len_prev / epoch), mark the code in the round's bit map,
+//     make room in the overflow array
+__global__ __launch_bounds__(256) void index_grow_kernel(IndexLine *__restrict__ lines, uint32_t *__restrict__ pool,
+                                                        uint32_t *__restrict__ pool_used, uint32_t pool_cap,
+                                                        const uint32_t *__restrict__ touched,
+                                                        const uint32_t *__restrict__ n_touched, uint32_t touched_cap,
+                                                        uint32_t epoch, uint32_t *__restrict__ newbits,
+                                                        uint32_t *__restrict__ err) {
+    const uint32_t n = min(*n_touched, touched_cap);
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const uint32_t code = touched[t];
+        IndexLine &L = lines[code];
+        const uint32_t p = L.pending, len = L.len;
+        L.pending = 0u;
+        if (L.epoch != epoch) { L.len_prev = len; L.epoch = epoch; }
+        atomicOr(&newbits[code >> 5], 1u << (code & 31u));
+        const uint32_t need = len + p;
+        if (need <= kInline) continue;
+        const uint32_t novf = need - kInline, old = L.ovf, cap = old ? pool[old] : 0u;
+        if (novf <= cap) continue;
+        const uint32_t ncap = max(2u * novf, 32u);
+        const uint32_t idx = atomicAdd(pool_used, ncap + 1u);
+        if ((uint64_t)idx + ncap + 1u > pool_cap) { *err = 2u; continue; }
+        pool[idx] = ncap;
+        const uint32_t have = len > kInline ? len - kInline : 0u;
+        for (uint32_t i = 0; i < have; ++i) pool[idx + 1u + i] = pool[old + 1u + i];
+        L.ovf = idx;
+    }
+}
+// (3) write the entries
+__global__ __launch_bounds__(256) void index_write_kernel(DevSeqs S, const uint32_t *__restrict__ list,
+                                                         const uint32_t *__restrict__ d_lo,
+                                                         const uint32_t *__restrict__ d_hi,
+                                                         IndexLine *__restrict__ lines, uint32_t *__restrict__ pool) {
+    const uint32_t lane = threadIdx.x & 63u, lo = *d_lo, hi = *d_hi;
+    for (uint32_t w = lo + blockIdx.x * 4 + (threadIdx.x >> 6); w < hi; w += gridDim.x * 4) {
+        const uint32_t k = list[w];
+        const uint64_t o = S.off[k];
+        const uint32_t nw = S.wcnt[k];
+        for (uint32_t i = lane; i < nw; i += 64) {
+            const uint32_t code = S.wcode[o + i];
+            IndexLine &L = lines[code];
+            const uint32_t pos = atomicAdd(&L.len, 1u);
+            const uint32_t entry = k | (S.wmult[o + i] > 1 ? kMultiBit : 0u);
+            if (pos < kInline) L.e[pos] = entry;
+            else pool[L.ovf + 1u + (pos - kInline)] = entry;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// filter: the short-word counting filter, query-major over the word index
+// ----------------------------------------------------------------------------------------
+// One wave per window slot (a query strand). The wave walks the query's distinct words, one word per
+// lane and 64-byte line per word, and counts min(mult_q, mult_r) per representative r < q:
+//   pass 1  counts into 1024 hashed LDS buckets (one LDS atomic per posting entry). A bucket sums the
+//           counts of every representative that hashes to it, so it can only over-count: a
+//           representative whose bucket stays below the query's threshold is certainly no candidate.
+//           Nearly every entry a query meets is a chance hit of a single word and ends here.
+//   pass 2  (only when some bucket reached the threshold) walks the lines again -- they are L2
+//           hits now -- and accumulates, exactly, count and smallest shared code for the
+//           representatives of hot buckets in a small LDS hash table (compare-and-swap insertion).
+//           If that table overflows, the representatives are split by residue class of a second
+//           hash and the pass is repeated per class, refined until every class fits.
+// Candidates reaching the threshold are emitted as pair records, pruned by the query's current
+// best key. NEWONLY visits only the entries appended in round `epoch` (the window's new
+// representatives; the round's bit map of touched codes saves the line reads elsewhere).
+// Every visited entry with r < q counts as a posting visit of the sequential rule, whatever the
+// query's state; final queries (`done`) only count.
+constexpr int kFB = 1024;          // buckets per wave
+constexpr int kFH = 256;           // exact table slots per wave
+constexpr uint32_t kFProbe = 24;   // probes before the exact table counts as full
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr int kFWork = 32;         // residue-class work list per wave
+constexpr unsigned long long kNoBest = ~0ull;
+
+struct FilterArgs {
+    const IndexLine *lines;
+    const uint32_t *pool;
+    const uint32_t *newbits;
+    const uint32_t *d_round_lo, *d_round_hi;  // NEWONLY: the round's representatives list[lo, hi): nothing to do when empty
+    uint32_t epoch;
+    uint32_t b0, nbq, ns;
+    uint32_t shard_index, shard_count;
+    const int32_t *req_aan;
+    const unsigned long long *best;
+    const uint8_t *done;
+    Pair *pairs;
+    uint32_t *n_pairs;
+    uint32_t pair_cap;
+    unsigned long long *visits, *rc_visits;
+    uint32_t *err;
+};
+
+// multiplicity of `code` in the word list of sequence r (present by construction of the index);
+// rare (the word is repeated in the query AND in the representative): kept out of line
+__device__ __noinline__ uint32_t word_mult_of(const uint32_t *__restrict__ wcode, const uint16_t *__restrict__ wmult,
+                                              uint64_t o, uint32_t n, uint32_t code) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (wcode[o + mid] < code) lo = mid + 1; else hi = mid;
+    }
+    return wmult[o + lo];
+}
+
+struct FilterWave {   // a wave's private LDS
+    uint32_t *bucket, *hrep, *hcnt, *hminc;
+    uint4 *lq;
+};
+
+// exact table: slot of representative r (inserted if absent), or kFH when the table is full
+__device__ __forceinline__ uint32_t exact_slot(uint32_t *hrep, uint32_t r) {
+    uint32_t h = (r * 0xC2B2AE35u) >> 24;         // 8 bits
+    for (uint32_t probe = 0; probe < kFProbe; ++probe) {
+        const uint32_t cur = hrep[h];
+        if (cur == r) return h;
+        if (cur == kEmpty) {
+            const uint32_t was = atomicCAS(&hrep[h], kEmpty, r);
+            if (was == kEmpty || was == r) return h;
+        }
+        h = (h + 1u) & (kFH - 1u);
+    }
+    return (uint32_t)kFH;
+}
+
+// One walk over the words [0, nw) at `o` of a query strand. PASS2 = false: count into the buckets
+// (`visits`, `hot`); true: accumulate the representatives of hot buckets whose residue class is
+// (class_k, class_j) in the exact table (`full` when it overflows).
+template <bool NEWONLY, bool PASS2>
+__device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &A, const FilterWave &W, uint32_t lane,
+                                            uint64_t o, uint32_t nw, uint32_t q, uint32_t thr, bool count_only,
+                                            uint32_t class_k, uint32_t class_j, uint32_t &visits, bool &hot,
+                                            bool &full) {
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    auto entry_visit = [&](uint32_t entry, uint32_t code, uint32_t mq) {
+        const uint32_t r = entry & ~kMultiBit;
+        if (r >= q) return;                      // only representatives created before the query
+        uint32_t c = 1u;
+        if (mq > 1u && (entry & kMultiBit)) {
+            const uint32_t mr = word_mult_of(S.wcode, S.wmult, S.off[r], S.wcnt[r], code);
+            c = mr < mq ? mr : mq;
+        }
+        const uint32_t b = (r * 0x9E3779B1u) >> 22;   // 10 bits
+        if (!PASS2) {
+            ++visits;
+            if (count_only) return;
+            const uint32_t old = atomicAdd(&W.bucket[b], c);
+            hot |= old + c >= thr;
+        } else {
+            if (W.bucket[b] < thr) return;
+            if (((((r ^ (r >> 15)) * 0x85EBCA6Bu) >> 9) & (class_k - 1u)) != class_j) return;
+            const uint32_t h = exact_slot(W.hrep, r);
+            if (h == (uint32_t)kFH) { full = true; return; }
+            atomicAdd(&W.hcnt[h], c);
+            atomicMin(&W.hminc[h], code);
+        }
+    };
+    for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+        const uint32_t w = w0 + lane;
+        bool live = w < nw;
+        const uint32_t code = live ? S.wcode[o + w] : 0u;
+        const uint32_t mq = live ? S.wmult[o + w] : 0u;
+        if (NEWONLY && live) live = (A.newbits[code >> 5] >> (code & 31u)) & 1u;
+        uint4 la = make_uint4(0u, 0u, 0u, 0u), lb = la, lc = la, ld = la;
+        if (live) {
+            const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + code);
+            la = lp[0]; lb = lp[1]; lc = lp[2]; ld = lp[3];
+        }
+        // line = { len, ovf, len_prev, epoch | pending, e0, e1, e2 | e3..e6 | e7..e10 }
+        const uint32_t hi = la.x;
+        const uint32_t lo = NEWONLY ? (la.w == A.epoch ? la.z : hi) : 0u;
+        const uint32_t hi_in = hi < kInline ? hi : kInline;
+        for (uint32_t j = lo; j < hi_in; ++j) {
+            uint32_t e = lb.y;                     // entry j, picked from the line's registers
+            e = j == 1 ? lb.z : e; e = j == 2 ? lb.w : e; e = j == 3 ? lc.x : e; e = j == 4 ? lc.y : e;
+            e = j == 5 ? lc.z : e; e = j == 6 ? lc.w : e; e = j == 7 ? ld.x : e; e = j == 8 ? ld.y : e;
+            e = j == 9 ? ld.z : e; e = j == 10 ? ld.w : e;
+            entry_visit(e, code, mq);
+        }
+        // lists longer than the line: queued, then walked by the whole wave with coalesced loads
+        const bool longl = hi > kInline && hi > lo;
+        const unsigned long long lm = __ballot(longl);
+        if (lm) {
+            if (longl) {
+                const uint32_t from = lo > kInline ? lo : kInline;
+                W.lq[__popcll(lm & lt_mask)] = make_uint4(la.y + 1u + (from - kInline), hi - from, code, mq);
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)   // TABLE: is the word in the batch at all? (0.5 MB bit map, L2-resident)
-                if (MODE == MODE_TABLE && live[t]) live[t] = (present[code[t] >> 5] >> (code[t] & 31u)) & 1u;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                // offsets code and code + 1 in ONE 8-byte gather (dword-aligned)
-                lh[t] = *reinterpret_cast<const u32x2_a4 *>(bi_off + (live[t] ? code[t] : 0u));
-                if (!live[t]) lh[t].y = lh[t].x;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t nl = (uint32_t)__popcll(lm);
+            for (uint32_t i = 0; i < nl; ++i) {
+                const uint4 it = W.lq[i];
+                for (uint32_t e = lane; e < it.y; e += 64) entry_visit(A.pool[it.x + e], it.z, it.w);
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint32_t lo = lh[t].x, hi = lh[t].y;
-                if (hi - lo > kLongMin) {
-                    const uint32_t slot = atomicAdd(&n_long, 1u);
-                    if (slot < kLongCap) {
-                        lq_lo[slot] = lo; lq_meta[slot] = ((hi - lo) << 16) | m[t]; lq_code[slot] = code[t];
-                        continue;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {   // LDS writes of this wave's lanes visible to all its lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool NT, bool NEWONLY>
+__global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][kFB];
+    __shared__ uint32_t s_hrep[4][kFH], s_hcnt[4][kFH], s_hminc[4][kFH];
+    __shared__ uint4 s_lq[4][64];
+    __shared__ uint2 s_work[4][kFWork];
+    if (NEWONLY && *A.d_round_lo >= *A.d_round_hi) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const FilterWave W{s_bucket[wave], s_hrep[wave], s_hcnt[wave], s_hminc[wave], s_lq[wave]};
+    uint2 *work = s_work[wave];
+    for (uint32_t i = lane; i < kFB; i += 64) W.bucket[i] = 0u;
+    for (uint32_t i = lane; i < kFH; i += 64) { W.hrep[i] = kEmpty; W.hcnt[i] = 0u; W.hminc[i] = kSentinel; }
+    wave_lds_sync();
+
+    for (uint32_t s = blockIdx.x * 4 + wave; s < A.ns; s += gridDim.x * 4) {
+        const uint32_t ql = s < A.nbq ? s : s - A.nbq;
+        if (A.shard_count > 1 && ql % A.shard_count != A.shard_index) continue;   // another process's member
+        const uint32_t q = A.b0 + ql;                     // the query (real sequence); candidates are r < q
+        const uint32_t k = slot_seq(S, A.b0, A.nbq, s);   // the strand walked
+        const bool count_only = NEWONLY && A.done[ql];
+        const int32_t t0 = A.req_aan[q];
+        const uint32_t thr = t0 > 1 ? (uint32_t)t0 : 1u;
+        const uint64_t o = S.off[k];
+        const uint32_t nw = S.wcnt[k];
+        uint32_t visits = 0;
+        bool hot = false, full = false;
+        filter_walk<NEWONLY, false>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full);
+        wave_lds_sync();
+        for (int d = 32; d > 0; d >>= 1) visits += __shfl_xor(visits, d);
+        if (visits && lane == 0) {
+            if (NT && s >= A.nbq) atomicAdd(&A.rc_visits[ql], (unsigned long long)visits);
+            else atomicAdd(A.visits, (unsigned long long)visits);
+        }
+        if (__ballot(hot)) {
+            // exact pass per residue class of the hot representatives, refined while the table overflows
+            uint32_t n_work = 1;
+            if (lane == 0) work[0] = make_uint2(1u, 0u);
+            wave_lds_sync();
+            while (n_work) {
+                const uint2 cls = work[n_work - 1];
+                --n_work;
+                full = false;
+                filter_walk<NEWONLY, true>(S, A, W, lane, o, nw, q, thr, false, cls.x, cls.y, visits, hot, full);
+                wave_lds_sync();
+                const bool over = __ballot(full) != 0ull;
+                if (over) {
+                    if (cls.x >= (1u << 20) || n_work + 4 > (uint32_t)kFWork) { if (lane == 0) *A.err = 3u; n_work = 0; }
+                    else {
+                        if (lane < 4) work[n_work + lane] = make_uint2(cls.x * 4u, cls.y + lane * cls.x);
+                        n_work += 4;
                     }
                 }
-                for (uint32_t e = lo; e < hi; ++e) visit(bi_ent[e], m[t], code[t]);
-            }
-        }
-        if (r + G < ntable) {  // the next entry's offsets have arrived by now: its first word codes
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint32_t i = threadIdx.x + t * THREADS;
-                code_nx[t] = i < n_nx ? S.wcode[o_nx + i] : 0u;
-                m_nx[t] = i < n_nx ? S.wmult[o_nx + i] : 0u;
-            }
-        }
-        __syncthreads();
-        const uint32_t nl = n_long < kLongCap ? n_long : kLongCap;   // (workgroup-uniform)
-        if (nl) {
-            const uint32_t lane = threadIdx.x & 63u;
-            for (uint32_t w = threadIdx.x >> 6; w < nl; w += THREADS / 64) {
-                const uint32_t lo = lq_lo[w], len = lq_meta[w] >> 16, m = lq_meta[w] & 0xFFFFu, code = lq_code[w];
-                // four coalesced loads in flight per wave: the walk is bound by their latency
-                for (uint32_t e = lane; e < len; e += 256) {
-                    uint32_t v[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = e + 64u * t < len ? bi_ent[lo + e + 64u * t] : 0u;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) if (e + 64u * t < len) visit(v[t], m, code);
+                for (uint32_t h = lane; h < (uint32_t)kFH; h += 64) {
+                    const uint32_t r = W.hrep[h];
+                    if (r == kEmpty) continue;
+                    const uint32_t c = W.hcnt[h], mc = W.hminc[h];
+                    W.hrep[h] = kEmpty; W.hcnt[h] = 0u; W.hminc[h] = kSentinel;
+                    if (over || c < thr) continue;
+                    const unsigned long long key = ((unsigned long long)(s >= A.nbq) << 63) | ((unsigned long long)mc << 32) | r;
+                    if (NEWONLY) {   // only candidates whose key can still beat the member's current best
+                        const unsigned long long bo = A.best[ql];
+                        if (bo != kNoBest && key > bo) continue;
+                    }
+                    const uint32_t slot = atomicAdd(A.n_pairs, 1u);
+                    if (slot < A.pair_cap) {
+                        Pair p;
+                        p.q = k; p.r = r; p.cnt = c; p.minc = mc;
+                        p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
+                        A.pairs[slot] = p;
+                    }
                 }
+                wave_lds_sync();
             }
         }
-        if (nl) __syncthreads();
-        if (my_visits) atomicAdd(&wg_visits, (unsigned long long)my_visits);
-        auto finish = [&](uint32_t q) {  // counters of batch slot q -> candidate pair record
-            const uint32_t c = cnt[q];
-            const uint32_t ql = q >= nbq ? q - nbq : q;  // the query's local index; q >= nbq = reverse strand
-            if (NT && (MODE == MODE_TABLE || MODE == MODE_NEW) && rc_visits && q >= nbq && vis[q])
-                atomicAdd(&rc_visits[ql], (unsigned long long)vis[q]);
-            if (c == 0u || (int32_t)c < req_aan[b0 + ql]) return;
-            if (MODE == MODE_NEW) {
-                if (qflag[ql]) return;  // resolved inside a block already
-                // only candidates whose key can still beat the query's current best. The WHOLE key is
-                // compared: with the same strand and smallest shared word, a new representative found
-                // later (in a block) but standing EARLIER in the order than the current one still wins.
-                const unsigned long long bo = best[ql];
-                const unsigned long long cand = ((unsigned long long)(q >= nbq) << 63) | ((unsigned long long)minc[q] << 32) | kNewBit | k;
-                if (bo != kNoBest && cand > bo) return;
+        if (visits && !count_only) {
+            for (uint32_t i = lane * 4; i < (uint32_t)kFB; i += 256) *reinterpret_cast<uint4 *>(&W.bucket[i]) = make_uint4(0u, 0u, 0u, 0u);
+            wave_lds_sync();
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// in-block pairs: every (later, earlier) pair of a block of still-open members, exactly
+// ----------------------------------------------------------------------------------------
+// The fallback after the discovery rounds: the block (<= kBlockCap members, in order) is resolved
+// exactly -- all its in-block candidate pairs are found here, evaluated, and the host walks the
+// block in order. One wave per (member strand, earlier member): the earlier member's word list is
+// streamed (coalesced), each lane looks its word up in the later member's sorted list.
+__global__ __launch_bounds__(256) void block_pairs_kernel(DevSeqs S, const uint32_t *__restrict__ blk,
+                                                         const uint32_t *__restrict__ d_nblk, uint32_t b0,
+                                                         uint32_t both, const int32_t *__restrict__ req_aan,
+                                                         Pair *__restrict__ pairs, uint32_t *__restrict__ n_pairs,
+                                                         uint32_t pair_cap, uint8_t *__restrict__ has_cand) {
+    const uint32_t n = *d_nblk, lane = threadIdx.x & 63u;
+    const uint32_t strands = both ? 2u : 1u;
+    const uint64_t total = (uint64_t)n * (n - 1) / 2 * strands;
+    for (uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += (uint64_t)gridDim.x * 4) {
+        const uint32_t strand = (uint32_t)(w % strands);
+        const uint64_t pi = w / strands;
+        // pair index -> (i, j), j < i: i = the largest with i (i - 1) / 2 <= pi
+        uint32_t i = (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)pi)) * 0.5);
+        while ((uint64_t)i * (i - 1) / 2 > pi) --i;
+        while ((uint64_t)(i + 1) * i / 2 <= pi) ++i;
+        const uint32_t j = (uint32_t)(pi - (uint64_t)i * (i - 1) / 2);
+        const uint32_t q = blk[i], r = blk[j];               // r earlier than q (the block list is in order)
+        const uint32_t kq = strand ? S.n_fwd + q : q;
+        const uint64_t oq = S.off[kq], orr = S.off[r];
+        const uint32_t nq = S.wcnt[kq], nr = S.wcnt[r];
+        uint32_t cnt = 0, minc = kSentinel;
+        for (uint32_t t = lane; t < nr; t += 64) {
+            const uint32_t code = S.wcode[orr + t];
+            uint32_t lo = 0, hi = nq;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (S.wcode[oq + mid] < code) lo = mid + 1; else hi = mid;
             }
-            if (MODE == MODE_BLOCK && !qflag[ql]) return;  // not in the current block
-            if (MODE == MODE_BLOCK) mark_out[ql] = 1;        // this block member has an earlier in-block candidate
+            if (lo < nq && S.wcode[oq + lo] == code) {
+                const uint32_t a = S.wmult[oq + lo], b = S.wmult[orr + t];
+                cnt += a < b ? a : b;
+                minc = code < minc ? code : minc;
+            }
+        }
+        for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_xor(cnt, d); const uint32_t m = __shfl_xor(minc, d); minc = m < minc ? m : minc; }
+        if (lane == 0 && cnt != 0u && (int32_t)cnt >= req_aan[q]) {
+            has_cand[q - b0] = 1;
             const uint32_t slot = atomicAdd(n_pairs, 1u);
             if (slot < pair_cap) {
                 Pair p;
-                p.q = slot_seq(S, b0, nbq, q); p.r = MODE == MODE_TABLE ? rep_index : k; p.cnt = c; p.minc = minc[q];
+                p.q = kq; p.r = r; p.cnt = cnt; p.minc = minc;
                 p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
                 pairs[slot] = p;
             }
-        };
-        for (uint32_t q4 = threadIdx.x * 4; q4 < nb; q4 += THREADS * 4) {
-            const uint4 c = *reinterpret_cast<const uint4 *>(&cnt[q4]);
-            const uint32_t mx = max(max(c.x, c.y), max(c.z, c.w));
-            if (mx == 0u && !NT) continue;               // untouched group: nothing to emit, nothing to clear
-            // (nucleotide reverse-strand visits are attributed per query: every slot is looked at)
-            if ((NT && MODE != MODE_BLOCK) || mx >= tmin) {
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) if (q4 + j < nb) finish(q4 + j);
-            }
-            *reinterpret_cast<uint4 *>(&cnt[q4]) = zero4;
-            *reinterpret_cast<uint4 *>(&minc[q4]) = sent4;
-            if (NT) *reinterpret_cast<uint4 *>(&vis[q4]) = zero4;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {   // consume and reset this entry's copies; the next entry uses the other pair
-            if ((MODE == MODE_TABLE || MODE == MODE_NEW) && visits && wg_visits) atomicAdd(visits, wg_visits);
-            wg_visits = 0ull; n_long = 0u;
         }
     }
 }
 
-// Pick the next block: the first `block_cap` batch members, in order, that are not final
-// (`done`) and have no accepted representative yet. One workgroup of 1024 threads, 4
-// consecutive members per thread, ordered by an exclusive scan.
-// counters[0] = block size, counters[1] = number of such members in total.
-__global__ __launch_bounds__(1024) void select_block_kernel(const unsigned long long *__restrict__ best,
-                                                           uint8_t *__restrict__ done,
-                                                           uint8_t *__restrict__ inblk, uint32_t b0,
-                                                           uint32_t nb, uint32_t block_cap,
-                                                           uint32_t *__restrict__ blk_list,
-                                                           uint32_t *__restrict__ counters,
-                                                           uint32_t *__restrict__ n_k,
-                                                           unsigned long long *__restrict__ zero8k) {
-    __shared__ uint32_t part[1024];
-    static_assert(2 * kBatchCap == 1024 * 8, "has_cand + accepted are cleared by this kernel, 8 bytes per thread");
-    zero8k[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) *n_k = 0u;
-    constexpr int PER = kBatchCap / 1024;
+// ----------------------------------------------------------------------------------------
+// window state: open members, discovery of certain representatives, blocks
+// ----------------------------------------------------------------------------------------
+constexpr int kSelThreads = 1024;
+// Pick the next block: the first `block_cap` window members, in order, that are not final (`done`)
+// and have no accepted representative yet. One workgroup, consecutive members per thread, ordered
+// by an exclusive scan. counters[0] = block size, counters[1] = number of such members in total.
+__global__ __launch_bounds__(kSelThreads) void select_block_kernel(const unsigned long long *__restrict__ best,
+                                                                  uint8_t *__restrict__ done,
+                                                                  uint8_t *__restrict__ inblk, uint32_t b0,
+                                                                  uint32_t nb, uint32_t block_cap,
+                                                                  uint32_t *__restrict__ blk_list,
+                                                                  uint32_t *__restrict__ counters,
+                                                                  uint32_t *__restrict__ n_k,
+                                                                  uint8_t *__restrict__ hascand_accepted,
+                                                                  uint32_t window_cap) {
+    __shared__ uint32_t part[kSelThreads];
     const uint32_t tid = threadIdx.x;
-    bool cand[PER];
+    for (uint32_t i = tid; i < 2 * window_cap / 8; i += kSelThreads) reinterpret_cast<unsigned long long *>(hascand_accepted)[i] = 0ull;
+    if (tid == 0) *n_k = 0u;
+    const uint32_t per = (nb + kSelThreads - 1) / kSelThreads;
+    const uint32_t q0 = tid * per, q1 = min(nb, q0 + per);
     uint32_t c = 0;
-    for (int t = 0; t < PER; ++t) {
-        const uint32_t q = tid * PER + t;
-        if (q < nb && inblk[q]) { done[q] = 1; inblk[q] = 0; }  // retire the previous block
-        cand[t] = q < nb && !done[q] && best[q] == kNoBest;
-        c += cand[t];
+    for (uint32_t q = q0; q < q1; ++q) {
+        if (inblk[q]) { done[q] = 1; inblk[q] = 0; }  // retire the previous block
+        c += !done[q] && best[q] == kNoBest;
     }
     part[tid] = c;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    for (uint32_t d = 1; d < kSelThreads; d <<= 1) {
         const uint32_t v = tid >= d ? part[tid - d] : 0u;
         __syncthreads();
         part[tid] += v;
         __syncthreads();
     }
     uint32_t rank = part[tid] - c;
-    for (int t = 0; t < PER; ++t) {
-        if (!cand[t]) continue;
-        if (rank < block_cap) { blk_list[rank] = b0 + tid * PER + t; inblk[tid * PER + t] = 1; }
+    for (uint32_t q = q0; q < q1; ++q) {
+        if (done[q] || best[q] != kNoBest) continue;
+        if (rank < block_cap) { blk_list[rank] = b0 + q; inblk[q] = 1; }
         ++rank;
     }
-    if (tid == 1023) { counters[0] = part[tid] < block_cap ? part[tid] : block_cap; counters[1] = part[tid]; }
+    if (tid == kSelThreads - 1) { counters[0] = part[tid] < block_cap ? part[tid] : block_cap; counters[1] = part[tid]; }
 }
 
-// The sweep's still-unassigned members (not final, no accepted representative): list + flags.
+// Start of a discovery round: the window's still-open members (not final, no accepted
+// representative), and where the round's segment of the new-representative list begins.
 __global__ __launch_bounds__(256) void list_open_kernel(const unsigned long long *__restrict__ best,
                                                        const uint8_t *__restrict__ done, uint32_t b0, uint32_t nb,
                                                        uint32_t *__restrict__ ulist, uint32_t *__restrict__ n_open) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nb) return;
-    const bool open = !done[q] && best[q] == kNoBest;
-    if (open) ulist[atomicAdd(n_open, 1u)] = b0 + q;
+    if (!done[q] && best[q] == kNoBest) ulist[atomicAdd(n_open, 1u)] = b0 + q;
 }
-// Discovery of certain representatives in time linear in the sweep's words. first[code] holds,
-// tagged with the sweep's epoch, the earliest still-unassigned member whose word list has
-// `code` (stored as epoch << 12 | 4095 - member so that a plain atomicMax keeps the earliest
-// member of the newest epoch; no per-sweep reset).
-static_assert(kBatchCap <= 4096, "first-open tags keep the member in 12 bits");
+// Discovery of certain representatives in time linear in the open members' words. first[code]
+// holds, tagged with the round's epoch, the earliest open member whose word list has `code`
+// (epoch << 16 | 65535 - member: a plain atomicMax keeps the earliest member of the newest epoch;
+// no per-round reset).
 __global__ __launch_bounds__(256) void first_open_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
                                                         const uint32_t *__restrict__ n_open, uint32_t b0,
                                                         uint32_t epoch, uint32_t *__restrict__ first) {
@@ -603,27 +736,23 @@ __global__ __launch_bounds__(256) void first_open_kernel(DevSeqs S, const uint32
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
         const uint32_t k = ulist[w];
         const uint64_t o = S.off[k];
-        const uint32_t nw = S.wcnt[k], tag = (epoch << 12) | (4095u - (k - b0));
+        const uint32_t nw = S.wcnt[k], tag = (epoch << 16) | (65535u - (k - b0));
         for (uint32_t i = lane; i < nw; i += 64) atomicMax(&first[S.wcode[o + i]], tag);
     }
 }
-// A member can only have an earlier unassigned candidate r if it shares at least its word
-// threshold with r, and the words it shares with r are among its words that ANY earlier
-// unassigned member has. When even that count stays below the threshold (on both strands) the
-// member is a new representative for certain: listed (any order; they are numbered by sequence
-// order later) and retired. Typically that is the first member of every family that appears in
-// this sweep. One wave per member.
+// A member can only have an earlier open candidate r if it shares at least its word threshold with
+// r, and the words it shares with r are among its words that ANY earlier open member has. When even
+// that count stays below the threshold (on both strands) the member is a new representative for
+// certain: appended to the window's list of new representatives and made final. Typically that is
+// the first member of every family that appears in the window. One wave per member.
 __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
                                                      const uint32_t *__restrict__ n_open, uint32_t b0,
                                                      uint32_t both, uint32_t epoch,
                                                      const uint32_t *__restrict__ first,
                                                      const int32_t *__restrict__ req_aan,
                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ list,
-                                                     uint32_t *__restrict__ n_list,
-                                                     const uint32_t *__restrict__ snap_src,
-                                                     uint32_t *__restrict__ snap_dst) {
+                                                     uint32_t *__restrict__ n_list) {
     const uint32_t lane = threadIdx.x & 63u, n = *n_open;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *snap_dst = *snap_src;  // where the next pass's pair records begin
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
         const uint32_t k = ulist[w], ql = k - b0;
         bool cand = false;
@@ -634,7 +763,7 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
             uint32_t sum = 0;
             for (uint32_t i = lane; i < nw; i += 64) {
                 const uint32_t f = first[S.wcode[o + i]];
-                if ((f >> 12) == epoch && 4095u - (f & 4095u) < ql) sum += S.wmult[o + i];
+                if ((f >> 16) == epoch && 65535u - (f & 65535u) < ql) sum += S.wmult[o + i];
             }
             for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
             cand = sum != 0u && (int32_t)sum >= req_aan[k];
@@ -646,24 +775,52 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
     }
 }
 
+// small bookkeeping kernels -----------------------------------------------------------------
+// counters: [0] pairs of the window, [1] pairs of the block, [2] begin of the pair range to evaluate,
+// [3] block size, [4] open members, [5] new representatives of the window (list length),
+// [6] begin of the current round's segment of that list, [7] touched codes of the round,
+// [8] error flag, [9] open members of the round
+enum { C_NW = 0, C_NK = 1, C_EVAL0 = 2, C_BLK = 3, C_OPEN = 4, C_NEW = 5, C_SEG0 = 6, C_TOUCH = 7, C_ERR = 8, C_ROUND_OPEN = 9, C_COUNT = 16 };
+
 // block members are final once the host has walked the block
-__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb,
-                                    const uint32_t *__restrict__ snap_src, uint32_t *__restrict__ snap_dst) {
+__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q == 0) *snap_dst = *snap_src;  // where the next pass's pair records begin
     if (q < nb && inblk[q]) { done[q] = 1; inblk[q] = 0; }
 }
+// start of a round: the pair range and list segment that the round's kernels work on begin here
+__global__ void round_begin_kernel(uint32_t *__restrict__ c) {
+    c[C_EVAL0] = c[C_NW]; c[C_SEG0] = c[C_NEW]; c[C_TOUCH] = 0u; c[C_ROUND_OPEN] = 0u;
+}
+// a list of new representatives given by the host (block results): appended to the window's list
+__global__ __launch_bounds__(256) void push_list_kernel(const uint32_t *__restrict__ src, uint32_t n,
+                                                       uint32_t *__restrict__ list, uint32_t *__restrict__ c) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t base = c[C_SEG0];   // (= c[C_NEW] as round_begin left it; the new length is written by the next kernel)
+    if (i < n) list[base + i] = src[i];
+}
+__global__ void push_done_kernel(uint32_t n, uint32_t *__restrict__ c) { c[C_NEW] = c[C_SEG0] + n; }
 
-// Start of a sweep: counters, best keys, reverse-strand visit counters and member flags in one launch.
-__global__ __launch_bounds__(256) void sweep_init_kernel(uint32_t *__restrict__ counters,
-                                                        unsigned long long *__restrict__ best,
-                                                        unsigned long long *__restrict__ rc_visits,
-                                                        uint8_t *__restrict__ done_inblk) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // grid covers kBatchCap
-    if (q < 8) counters[q] = 0u;
+// Start of a window: counters, best keys, reverse-strand visit counters and member flags in one launch.
+__global__ __launch_bounds__(256) void window_init_kernel(uint32_t *__restrict__ counters,
+                                                         unsigned long long *__restrict__ best,
+                                                         unsigned long long *__restrict__ rc_visits,
+                                                         uint8_t *__restrict__ flags, uint32_t window_cap) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // grid covers window_cap
+    if (q < C_COUNT && q != C_ERR) counters[q] = 0u;
     best[q] = kNoBest;
     if (rc_visits) rc_visits[q] = 0ull;
-    if (q < 2 * kBatchCap / 8) reinterpret_cast<unsigned long long *>(done_inblk)[q] = 0ull;
+    if (q < 4 * window_cap / 8) reinterpret_cast<unsigned long long *>(flags)[q] = 0ull;
+}
+
+// record-sharded mode: element-wise minimum of the processes' best keys (gathered, one row per process)
+__global__ __launch_bounds__(256) void min_rows_kernel(const unsigned long long *__restrict__ rows, uint32_t n_rows,
+                                                      uint32_t row_stride, uint32_t n,
+                                                      unsigned long long *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long m = rows[i];
+    for (uint32_t r = 1; r < n_rows; ++r) { const unsigned long long v = rows[(size_t)r * row_stride + i]; m = v < m ? v : m; }
+    out[i] = m;
 }
 
 // One round trip's worth of results written straight into page-locked host memory: each
@@ -673,7 +830,7 @@ __global__ __launch_bounds__(256) void sweep_init_kernel(uint32_t *__restrict__ 
 constexpr uint32_t kPairWords = sizeof(Pair) / 4;
 static_assert(sizeof(Pair) % 4 == 0, "pair records are published as dwords");
 struct PubSeg { const uint32_t *src; uint32_t *dst; const uint32_t *count; uint32_t fixed, words, cap; };
-constexpr int kPubSegs = 6;
+constexpr int kPubSegs = 8;
 struct PubArgs { PubSeg seg[kPubSegs]; int n; };
 __global__ __launch_bounds__(256) void publish_kernel(PubArgs a) {
     for (int s = 0; s < a.n; ++s) {
@@ -1289,7 +1446,7 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
 }  // namespace
 
 // ========================================================================================
-// host side: one call = upload, word lists, sweeps, in-order resolution, download
+// host side: one call = upload, word lists, windows, in-order resolution, download
 // ========================================================================================
 namespace {
 
@@ -1335,7 +1492,7 @@ enum : uint8_t { ST_OPEN = 0, ST_MEMBER = 1, ST_REP = 2 };
 
 #define LAUNCH_CHECK() PGX_HIP(hipGetLastError())
 
-// The sweep loop waits on the stream thousands of times for a few tens of microseconds;
+// The window loop waits on the stream a few times per window for tens of microseconds;
 // polling returns as soon as the queue drains instead of after an interrupt wake-up.
 static double g_wait_s = 0.0;  // host time spent waiting for the stream (PGX_TRACE)
 static inline hipError_t spin_sync(hipStream_t st) {
@@ -1367,6 +1524,18 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                                uint8_t *out_strand, uint32_t *out_n_clusters,
                                pgx_cluster_stats *stats, void *stream_);
 
+extern "C" uint32_t pgx_cluster_window_cap(const pgx_cluster_params *P) {
+    if (!P) return 0;
+    const bool both = P->alphabet == 1 && P->both_strands != 0;
+    // nucleotide rules at the reference's -n 5 -c 0.8 pass any pair that shares one word: small windows
+    uint32_t w = P->alphabet == 1 ? (both ? 2048u : 4096u) : 16384u;
+    if (P->batch_size > 0) w = (uint32_t)P->batch_size;
+    if (const char *e = std::getenv("PGX_WINDOW")) { const long v = std::atol(e); if (v > 0) w = (uint32_t)v; }
+    w = std::max(w, 64u);
+    w = std::min(w, kWindowMax);
+    return (w + 63u) & ~63u;
+}
+
 extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_offsets,
                                       uint32_t n_in, uint64_t total_in, const pgx_cluster_params *P,
                                       int32_t *out_cluster, int32_t *out_member, float *out_identity,
@@ -1379,7 +1548,7 @@ extern "C" int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, c
         fprintf(stderr, "[pgx] call total (incl. clean-up)    %8.2f ms\n",
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     if (rc != PGX_OK && ctx) {
-        // a failed call may leave kernels in flight on either stream that use the context's workspace:
+        // a failed call may leave kernels in flight that use the context's workspace:
         // drain them, so that the context stays usable (the error text is the caller's to read)
         (void)hipStreamSynchronize(static_cast<hipStream_t>(stream_));
         (void)hipStreamSynchronize(ctx->stream2);
@@ -1403,10 +1572,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_REQUIRE(P->identity >= 0.4 && P->identity <= 1.0, "identity must be 0.4..1.0");
     PGX_REQUIRE(P->band_width >= 1 && P->band_width <= kMaxBand, "band_width must be 1..64");
     PGX_REQUIRE(P->min_length >= P->word_len - 1, "min_length must be at least word_len - 1");
+    PGX_REQUIRE(P->batch_size >= 0, "batch_size must not be negative");
     PGX_REQUIRE(P->shard_count >= 0 && (P->shard_count == 0 ? P->shard_index == 0 : (P->shard_index >= 0 && P->shard_index < P->shard_count)),
                 "shard_index must be in [0, shard_count)");
     PGX_REQUIRE(P->shard_count <= 1 || P->exchange, "shard_count > 1 needs an exchange callback");
-    PGX_REQUIRE(!P->exchange || P->exchange_keys, "the exchange callback needs exchange_keys (4096 uint64 in device memory)");
+    PGX_REQUIRE(!P->exchange || (P->exchange_send && P->exchange_recv),
+                "the exchange callback needs exchange_send / exchange_recv (PGX_EXCHANGE_KEYS uint64 per process, device memory)");
     PGX_HIP(hipSetDevice(ctx->device_id));
     hipStream_t st = (hipStream_t)stream_;
     const auto t_call0 = std::chrono::steady_clock::now();
@@ -1415,7 +1586,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     };
     const bool trace_phases = std::getenv("PGX_TRACE") != nullptr;
     double t_mark = 0.0;
-    auto phase = [&](const char *what) {   // PGX_TRACE: host wall time of the phases outside the sweep loop
+    auto phase = [&](const char *what) {   // PGX_TRACE: host wall time of the phases outside the window loop
         if (!trace_phases) return;
         const double now = ms_since(t_call0);
         fprintf(stderr, "[pgx] %-28s %8.2f ms\n", what, now - t_mark);
@@ -1463,6 +1634,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     for (uint32_t i = 0; i < n_in; ++i)
         if ((int)in_len[i] > P->min_length) order[bucket[max_len - in_len[i]]++] = i;
     if (n == 0) { if (stats) *stats = S; return PGX_OK; }
+    PGX_REQUIRE(n < 0x7FFFFFF0u, "too many sequences for 31-bit index entries");
 
     // sequences n .. 2n-1 are the reverse complements (nucleotides, both strands)
     const uint32_t nv = both ? 2 * n : n;
@@ -1503,27 +1675,28 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     // ---- device buffers ------------------------------------------------------------------
     uint32_t n_codes = 1;
     for (int t = 0; t < P->word_len; ++t) n_codes *= nt ? 4u : (uint32_t)kNAA1;
-    const uint32_t sweep_cap = both ? kBatchCap / 2 : kBatchCap;  // queries per sweep (each strand takes a slot)
-    uint32_t pair_cap = 4u << 20;  // grows per sweep for nucleotides, whose word filter passes almost every pair
+    const uint32_t window_cap = pgx_cluster_window_cap(P);           // queries per window
+    PGX_REQUIRE(!P->exchange || window_cap <= PGX_EXCHANGE_KEYS, "window larger than PGX_EXCHANGE_KEYS");
+    uint32_t pair_cap = 4u << 20;  // grows per window for nucleotides, whose word filter passes almost every pair
     const uint32_t pair_cap_k = kBlockCap * kBlockCap + 16;  // every pair of one block, both strands
-    uint64_t max_batch_words = 0;
-    for (uint32_t b0 = 0; b0 < n; b0 += sweep_cap) {
-        const uint32_t b1 = std::min(n, b0 + sweep_cap);
-        max_batch_words = std::max<uint64_t>(max_batch_words, (h_off[b1] - h_off[b0]) * (both ? 2 : 1));
+    uint64_t max_window_words = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += window_cap) {
+        const uint32_t b1 = std::min(n, b0 + window_cap);
+        max_window_words = std::max<uint64_t>(max_window_words, h_off[b1] - h_off[b0]);
     }
+    PGX_REQUIRE(max_window_words < 0xFFFFFFF0ull, "window too large");
     const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsCap;
     const uint32_t diag_grid = 8192, align_grid = 1024;  // diag: one wave per pair, ~11 workgroups fit a CU
     const uint32_t gs_stride = 3u * ((max_len + 64u) & ~63u);  // per workgroup: 2 L diagonals + L query positions
 
-    DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_rep_seq, d_bi_cnt, d_bi_off,
-        d_bi_ent, d_best_old, d_counters, d_visits, d_pairsA, d_pairsN, d_pairsK, d_blk_list, d_new_list,
-        d_flags, d_scan_tmp, d_gscratch, d_order, d_list, d_gather, d_bi_cnt2, d_bi_off2, d_bi_ent2,
-        d_pairsA2, d_scan_tmp2, d_nA2, d_pk, d_pkoff, d_first, d_present, d_present2;
+    DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_lines, d_pool[2], d_idx,
+        d_newbits, d_touched, d_first, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
+        d_ulist, d_new_list, d_flags, d_gscratch, d_order, d_list, d_gather, d_pk, d_pkoff;
     {   // all of them live in the context's workspace (slots 1..)
-        DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_rep_seq,
-                         &d_bi_cnt, &d_bi_off, &d_bi_ent, &d_best_old, &d_counters, &d_visits, &d_pairsA,
-                         &d_pairsN, &d_pairsK, &d_blk_list, &d_new_list, &d_flags, &d_scan_tmp, &d_gscratch, &d_order, &d_list, &d_gather,
-                         &d_bi_cnt2, &d_bi_off2, &d_bi_ent2, &d_pairsA2, &d_scan_tmp2, &d_nA2, &d_pk, &d_pkoff, &d_first, &d_present, &d_present2};
+        DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_lines,
+                         &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_best_own, &d_rcvis,
+                         &d_counters, &d_visits, &d_pairsW, &d_pairsK, &d_blk_list, &d_ulist, &d_new_list, &d_flags,
+                         &d_gscratch, &d_order, &d_list, &d_gather, &d_pk, &d_pkoff};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -1540,49 +1713,47 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_aa1.alloc((size_t)n * 4));
     PGX_HIP(d_aas.alloc((size_t)n * 4));
     PGX_HIP(d_aan.alloc((size_t)n * 4));
-    PGX_HIP(d_rep_seq.alloc((size_t)n * 4));
-    PGX_HIP(d_bi_cnt.alloc(((size_t)n_codes + 1) * 4));
-    PGX_HIP(hipMemsetAsync(d_bi_cnt.p, 0, ((size_t)n_codes + 1) * 4, st));  // once: every sweep leaves it zero again
-    PGX_HIP(d_bi_off.alloc(((size_t)n_codes + 1) * 4));
+    // the word index: all lines empty (one memset of n_codes * 64 B per call, e.g. 261 MB for protein 5-mers)
+    PGX_HIP(d_lines.alloc((size_t)n_codes * sizeof(IndexLine)));
+    PGX_HIP(hipMemsetAsync(d_lines.p, 0, (size_t)n_codes * sizeof(IndexLine), st));
+    PGX_HIP(d_idx.alloc(16));
+    PGX_HIP(d_newbits.alloc(((size_t)n_codes / 32 + 2) * 4));
+    PGX_HIP(d_touched.alloc((max_window_words + 16) * 4));
     PGX_HIP(d_first.alloc((size_t)n_codes * 4));
-    PGX_HIP(d_present.alloc(((size_t)n_codes / 32 + 2) * 4));
-    PGX_HIP(d_bi_ent.alloc((max_batch_words + 16) * 4));
-    PGX_HIP(d_best_old.alloc(kBatchCap * 16));  // best keys + reverse-strand visit counters
-    PGX_HIP(d_blk_list.alloc(kBatchCap * 4));
-    PGX_HIP(d_new_list.alloc(kBatchCap * 4));
-    PGX_HIP(d_flags.alloc(4 * kBatchCap));  // done, in-block, has-candidate, accepted
+    PGX_HIP(d_best_own.alloc((size_t)window_cap * 8));
+    PGX_HIP(d_rcvis.alloc((size_t)window_cap * 8));
+    PGX_HIP(d_blk_list.alloc(kBlockCap * 4));
+    PGX_HIP(d_ulist.alloc((size_t)window_cap * 4));
+    PGX_HIP(d_new_list.alloc((size_t)window_cap * 4));
+    PGX_HIP(d_flags.alloc(4 * (size_t)window_cap));  // done, in-block, has-candidate, accepted
     PGX_HIP(d_list.alloc((size_t)pair_cap_k * 4));
     PGX_HIP(d_gather.alloc((size_t)pair_cap_k * sizeof(Pair)));
-    PGX_HIP(d_counters.alloc(32));
+    PGX_HIP(d_counters.alloc(C_COUNT * 4));
+    PGX_HIP(hipMemsetAsync(d_counters.p, 0, C_COUNT * 4, st));
     PGX_HIP(d_visits.alloc(8));
-    PGX_HIP(d_pairsA.alloc((size_t)pair_cap * sizeof(Pair)));
-    PGX_HIP(d_pairsN.alloc((size_t)pair_cap * sizeof(Pair)));
+    PGX_HIP(d_pairsW.alloc((size_t)pair_cap * sizeof(Pair)));
     PGX_HIP(d_pairsK.alloc((size_t)pair_cap_k * sizeof(Pair)));
     if (need_gscratch) PGX_HIP(d_gscratch.alloc((size_t)diag_grid * gs_stride * 4));
-    size_t scan_bytes = 0;
-    PGX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(),
-                                             (int)(n_codes + 1), st));
-    PGX_HIP(d_scan_tmp.alloc(scan_bytes));
-    // Sweep pipelining (proteins): while sweep s resolves its members on the main stream, the
-    // side stream already builds the index of sweep s+1 and streams the representatives known
-    // so far against it; sweep s+1 then only adds the representatives created in sweep s.
-    const bool pipeline = !nt && n > sweep_cap;
-    PGX_HIP(d_nA2.alloc(64));
-    if (pipeline) {
-        PGX_HIP(d_bi_cnt2.alloc(((size_t)n_codes + 1) * 4));
-        PGX_HIP(hipMemsetAsync(d_bi_cnt2.p, 0, ((size_t)n_codes + 1) * 4, st));
-        PGX_HIP(d_bi_off2.alloc(((size_t)n_codes + 1) * 4));
-        PGX_HIP(d_bi_ent2.alloc((max_batch_words + 16) * 4));
-        PGX_HIP(d_pairsA2.alloc((size_t)pair_cap * sizeof(Pair)));
-        PGX_HIP(d_scan_tmp2.alloc(scan_bytes));
-        PGX_HIP(d_present2.alloc(((size_t)n_codes / 32 + 2) * 4));
+    // overflow pool of the index: sized before every window from the entries that exist and the most the
+    // window can add (every array is re-allocated with twice the need: <= 8 words per entry in all)
+    int pool_cur = 0;
+    uint64_t pool_cap = 0;
+    auto ensure_pool = [&](uint64_t entries) -> int {
+        const uint64_t need = 8 * entries + 4096;
+        if (need <= pool_cap) return PGX_OK;
+        if (need > 0xFFFFFFF0ull) { pgx_set_error("pgx_cluster_greedy: word index too large for 32-bit pool offsets"); return PGX_ERR_CAPACITY; }
+        const uint64_t want = std::min<uint64_t>(0xFFFFFFF0ull, need + need / 2);
+        DevBuf &nb_ = d_pool[pool_cur ^ 1];
+        PGX_HIP(nb_.alloc(want * 4));
+        if (pool_cap) PGX_HIP(hipMemcpyAsync(nb_.p, d_pool[pool_cur].p, pool_cap * 4, hipMemcpyDeviceToDevice, st));
+        pool_cur ^= 1;
+        pool_cap = want;
+        return PGX_OK;
+    };
+    {
+        const uint32_t one = 1u;   // pool word 0 is never an array: ovf == 0 means "no overflow array"
+        PGX_HIP(hipMemcpyAsync(d_idx.p, &one, 4, hipMemcpyHostToDevice, st));
     }
-    struct SweepBuf { uint32_t *bi_cnt, *bi_off, *bi_ent; Pair *pairsA; uint32_t *nA; void *scan_tmp; uint32_t *present; };
-    SweepBuf sbuf[2] = {
-        {d_bi_cnt.as<uint32_t>(), d_bi_off.as<uint32_t>(), d_bi_ent.as<uint32_t>(),
-         d_pairsA.as<Pair>(), d_nA2.as<uint32_t>(), d_scan_tmp.p, d_present.as<uint32_t>()},
-        {d_bi_cnt2.as<uint32_t>(), d_bi_off2.as<uint32_t>(), d_bi_ent2.as<uint32_t>(),
-         d_pairsA2.as<Pair>(), d_nA2.as<uint32_t>() + 8, d_scan_tmp2.p, d_present2.as<uint32_t>()}};
 
     PGX_HIP(d_order.alloc((size_t)n * 4));
     PGX_HIP(hipMemcpyAsync(d_order.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1635,293 +1806,223 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(hipMemcpyAsync(h_wcnt.data(), d_wcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 
     phase("word lists (enqueue)");
-    // ---- sweeps ---------------------------------------------------------------------------
+    // ---- windows --------------------------------------------------------------------------
     std::vector<uint32_t> rep_seq;            // representative index -> sorted sequence index
     HostVec<int32_t> cluster_of(ctx, 9, n, -1);   // sorted sequence index -> cluster
     HostVec<int32_t> iden_of(ctx, 10, n, -1);     // identical residues against the representative, -1 = is one
     PGX_REQUIRE(cluster_of.ok() && iden_of.ok(), "out of host memory");
-    Pinned<Pair> hA, hN, hK;
-    Pinned<unsigned long long> h_best;
-    Pinned<uint32_t> h_cnt, h_blk;
-    Pinned<uint32_t> h_new, h_rep_stage[2];
-    hA.bind(ctx, 0); hN.bind(ctx, 1); hK.bind(ctx, 2); h_best.bind(ctx, 3); h_cnt.bind(ctx, 4); h_blk.bind(ctx, 5);
-    h_new.bind(ctx, 6); h_rep_stage[0].bind(ctx, 7); h_rep_stage[1].bind(ctx, 8);
-    PGX_HIP(h_rep_stage[0].reserve(kBatchCap)); PGX_HIP(h_rep_stage[1].reserve(kBatchCap));
-    constexpr uint32_t kPrefix = 4096;  // initial capacity (records) of the host copies of the phase-A / new-representative pairs
-    PGX_HIP(h_best.reserve(kBatchCap)); PGX_HIP(h_cnt.reserve(8)); PGX_HIP(h_blk.reserve(kBatchCap));
-    PGX_HIP(h_new.reserve(kBatchCap)); PGX_HIP(hK.reserve(pair_cap_k)); PGX_HIP(hA.reserve(kPrefix)); PGX_HIP(hN.reserve(kPrefix));
-    // device counters: [1] pairsN, [2] pairsK, [3] pairsN range start, [4] open members / block size,
-    // [5] open members left, [6] certain representatives of the sweep
-    uint32_t *d_nN = d_counters.as<uint32_t>() + 1, *d_nK = d_nN + 1, *d_nN0 = d_nN + 2, *d_blk = d_nN + 3,
-             *d_ncertain = d_counters.as<uint32_t>() + 6;
-    uint32_t head_ready = 0xFFFFFFFFu, head_reps = 0;  // sweep whose head already runs on the side stream
-    Pinned<uint32_t> h_nA;
-    h_nA.bind(ctx, 10);
-    PGX_HIP(h_nA.reserve(4));
-    unsigned long long *d_rcvis = d_best_old.as<unsigned long long>() + kBatchCap;
-    unsigned long long *d_best = P->exchange ? static_cast<unsigned long long *>(P->exchange_keys)
-                                             : d_best_old.as<unsigned long long>();
-    // table-sharded mode (see pgx.h): this process streams the representatives index % shard_count == shard_index
+    Pinned<Pair> hW, hK;
+    Pinned<unsigned long long> h_best, h_rcvis;
+    Pinned<uint32_t> h_cnt, h_blk, h_new, h_list, h_push;
+    Pinned<Pair> h_gather;
+    hW.bind(ctx, 0); hK.bind(ctx, 1); h_best.bind(ctx, 2); h_cnt.bind(ctx, 3); h_blk.bind(ctx, 4);
+    h_new.bind(ctx, 5); h_rcvis.bind(ctx, 6); h_list.bind(ctx, 7); h_gather.bind(ctx, 8); h_push.bind(ctx, 9);
+    constexpr uint32_t kPrefix = 65536;  // initial capacity (records) of the host copy of the window's pairs
+    PGX_HIP(h_best.reserve(window_cap)); PGX_HIP(h_cnt.reserve(C_COUNT)); PGX_HIP(h_blk.reserve(kBlockCap));
+    PGX_HIP(h_new.reserve(window_cap)); PGX_HIP(hK.reserve(pair_cap_k)); PGX_HIP(hW.reserve(kPrefix));
+    PGX_HIP(h_rcvis.reserve(window_cap)); PGX_HIP(h_push.reserve(window_cap));
+    PGX_HIP(h_list.reserve(pair_cap_k)); PGX_HIP(h_gather.reserve(pair_cap_k));
+    uint32_t *dc = d_counters.as<uint32_t>();
+    unsigned long long *d_rcvis_p = d_rcvis.as<unsigned long long>();
+    // record-sharded mode (see pgx.h): this process filters and aligns the window members ql % shard_count ==
+    // shard_index; the window's best keys live in the caller's exchange buffer and are all-gathered after
+    // every evaluation
+    unsigned long long *d_best = P->exchange ? static_cast<unsigned long long *>(P->exchange_send)
+                                             : d_best_own.as<unsigned long long>();
     const uint32_t shard_count = P->shard_count > 0 ? (uint32_t)P->shard_count : 1u;
     const uint32_t shard_index = P->shard_count > 0 ? (uint32_t)P->shard_index : 0u;
     const bool count_replicated = shard_index == 0;  // work every process repeats is counted by the first one only
-    auto owned_reps = [&](uint32_t lo, uint32_t hi, uint32_t *first, uint32_t *count) {
-        *first = lo + (shard_index + shard_count - lo % shard_count) % shard_count;
-        *count = *first < hi ? (hi - *first + shard_count - 1) / shard_count : 0u;
-    };
-    uint64_t own_rep_words = 0;  // distinct words of the representatives this process streams
-    Pinned<unsigned long long> h_rcvis;
-    h_rcvis.bind(ctx, 9);
-    PGX_HIP(h_rcvis.reserve(kBatchCap));
     uint64_t visits_rc = 0;
-    uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + kBatchCap;
-    std::vector<uint8_t> status(kBatchCap), won_new(kBatchCap);
+    uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + window_cap;
+    uint8_t *d_hascand = d_done + 2 * (size_t)window_cap, *d_accepted = d_done + 3 * (size_t)window_cap;
+    std::vector<uint8_t> status(window_cap);
     HostVec<uint8_t> strand_of(ctx, 11, n, (uint8_t)0);
     PGX_REQUIRE(strand_of.ok(), "out of host memory");
-    std::vector<unsigned long long> winner_key(kBatchCap);  // strand<<63 | minc<<32 | new<<31 | index of the winner
-    std::vector<uint32_t> member_of(kBatchCap), new_reps, order_k, rank_of(kBatchCap),
-        bucket_k(kBlockCap + 2), fill_k(kBlockCap + 2), flight;
+    std::vector<unsigned long long> winner_key(window_cap);  // strand<<63 | minc<<32 | sequence index of the winner
+    std::vector<uint32_t> new_reps, order_k, rank_of(window_cap), bucket_k(kBlockCap + 2), fill_k(kBlockCap + 2), flight;
     auto real = [&](uint32_t k) { return k >= n ? k - n : k; };
-    auto pair_key = [&](const Pair &pp, bool is_new) {
-        return ((unsigned long long)(pp.q >= n) << 63) | ((unsigned long long)pp.minc << 32) | (is_new ? kNewBit : 0u) | pp.r;
+    auto pair_key = [&](const Pair &pp) {
+        return ((unsigned long long)(pp.q >= n) << 63) | ((unsigned long long)pp.minc << 32) | pp.r;
     };
-    Pinned<uint32_t> h_list;
-    Pinned<Pair> h_gather;
-    h_list.bind(ctx, 11); h_gather.bind(ctx, 12);
-    PGX_HIP(h_list.reserve(pair_cap_k)); PGX_HIP(h_gather.reserve(pair_cap_k));
-    uint8_t *d_hascand = d_flags.as<uint8_t>() + 2 * kBatchCap, *d_accepted = d_hascand + kBatchCap;
     uint64_t n_rounds = 0;
 
-    uint64_t gpu_pairs = 0, gpu_aligned = 0, gpu_aligned_bytes = 0, table_stream_words = 0;  // actual device work (reserved stats slots)
-    auto account = [&](const Pair *pp, uint32_t cnt, bool via_rep) {
+    uint64_t gpu_pairs = 0, gpu_aligned = 0, gpu_aligned_bytes = 0, filter_walk_words = 0;  // actual device work (reserved stats slots)
+    auto account = [&](const Pair *pp, uint32_t cnt) {
         for (uint32_t i = 0; i < cnt; ++i) {
             ++gpu_pairs;
             if ((pp[i].flags & (F_DIAG_PASS | F_BAND_OK)) != (F_DIAG_PASS | F_BAND_OK)) continue;
             ++gpu_aligned;
-            gpu_aligned_bytes += h_len[pp[i].q] + h_len[via_rep ? rep_seq[pp[i].r] : pp[i].r];
+            gpu_aligned_bytes += h_len[pp[i].q] + h_len[pp[i].r];
         }
     };
     const bool trace = std::getenv("PGX_TRACE") != nullptr;
-    // table pass on the side stream: two workgroups per CU leave LDS and wave slots for the main
-    // stream's latency-bound kernels (256 made it twice as slow, 1024 gained 5% and cost the main path more)
-    const uint32_t side_grid = 512u;
-    phase("sweep set-up");
+    const uint32_t filter_grid = 4096u;
+    uint32_t epoch_idx = 0;      // append rounds of the index (line.epoch); 0 = never
+    uint32_t epoch_tag = 0;      // discovery rounds (first-open tags, 16 bits)
+    PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)n_codes * 4, st));
+    phase("window set-up");
     const auto t_loop0 = std::chrono::steady_clock::now();
     double t_resolve = 0.0, t_close = 0.0;
     uint64_t n_blocks = 0;
     g_wait_s = 0.0;
-    std::function<int()> deferred;  // bookkeeping of the sweep before, see the close of a sweep
-    for (uint32_t b0 = 0; b0 < n; b0 += sweep_cap) {
-        const uint32_t nb = std::min(sweep_cap, n - b0);  // queries of this sweep
-        const uint32_t ns = both ? 2 * nb : nb;           // batch slots: + one per reverse complement
+    std::function<int()> deferred;  // bookkeeping of the window before, see the close of a window
+    for (uint32_t b0 = 0; b0 < n; b0 += window_cap) {
+        const uint32_t nb = std::min(window_cap, n - b0);  // queries of this window
+        const uint32_t ns = both ? 2 * nb : nb;            // window slots: + one per reverse complement
         const uint32_t n_reps = (uint32_t)rep_seq.size();
-        table_stream_words += own_rep_words;  // every sweep streams the word lists of all (owned) representatives so far
-        if (nt) {  // at cd-hit-est's -n 5 -c 0.8 one shared word is enough: size the pair buffers for all pairs
+        const uint64_t window_words = h_off[b0 + nb] - h_off[b0];
+        { int rc = ensure_pool(S.rep_words + window_words); if (rc) return rc; }
+        uint32_t *d_poolp = d_pool[pool_cur].as<uint32_t>();
+        if (nt) {  // at cd-hit-est's -n 5 -c 0.8 one shared word is enough: size the pair buffer for all pairs
             const uint64_t need = (uint64_t)ns * ((uint64_t)n_reps + nb) + 1024;
             if (need > (400ull << 20)) {
-                pgx_set_error("pgx_cluster_greedy: %llu candidate pairs in one sweep exceed the supported maximum",
+                pgx_set_error("pgx_cluster_greedy: %llu candidate pairs in one window exceed the supported maximum",
                               (unsigned long long)need);
                 return PGX_ERR_CAPACITY;
             }
             if (need > pair_cap) {
                 PGX_HIP(spin_sync(st));
+                if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
                 pair_cap = (uint32_t)(need + need / 2);
-                PGX_HIP(d_pairsA.alloc((size_t)pair_cap * sizeof(Pair)));
-                PGX_HIP(d_pairsN.alloc((size_t)pair_cap * sizeof(Pair)));
-                sbuf[0].pairsA = d_pairsA.as<Pair>();
+                PGX_HIP(d_pairsW.alloc((size_t)pair_cap * sizeof(Pair)));
             }
         }
         S.sweeps++;
         const auto t_sweep0 = std::chrono::steady_clock::now();
         const uint64_t blocks_before = n_blocks;
         // the general (int64, one pair per wave) aligner is only needed when some pair of this
-        // sweep cannot use the 16-lane fast path: query length + longest sequence, or the band
+        // window cannot use the 16-lane fast path: query length + longest sequence, or the band
         const bool any_wide = P->band_width > 32 || (int)(h_len[b0] + max_len) > kA16MaxSum;
-        const uint32_t parity = (uint32_t)(S.sweeps & 1);
-        const SweepBuf &B = sbuf[pipeline ? parity : 0];
-        uint32_t *d_nA = B.nA;
-        // sweep head = index over the batch + the table pass against representatives [0, n_table);
-        // it only depends on the sweep's position, so it can run ahead on the side stream
-        // smallest word threshold among a sweep's queries (a candidate needs at least one shared word)
-        auto min_threshold = [&](uint32_t q0, uint32_t nq) {
-            int32_t t = INT32_MAX;
-            for (uint32_t q = q0; q < q0 + nq; ++q) t = std::min(t, std::max(h_aan[q], 1));
-            return (uint32_t)t;
-        };
-        const uint32_t tmin = min_threshold(b0, nb);
-        auto sweep_head = [&](const SweepBuf &W, uint32_t hb0, uint32_t hnb, uint32_t hns, uint32_t n_table,
-                              hipStream_t hs) -> int {
-            PGX_HIP(hipMemsetAsync(W.nA, 0, 4, hs));
-            {
-                ProfScope prof(ctx, "index_hist_kernel", hs);
-                index_hist_kernel<<<hns, 256, 0, hs>>>(DS, hb0, hns, hnb, W.bi_cnt);
-            }
-            LAUNCH_CHECK();
-            index_present_kernel<<<(n_codes + 255) / 256, 256, 0, hs>>>(W.bi_cnt, n_codes, W.present);
-            LAUNCH_CHECK();
-            {
-                ProfScope prof(ctx, "index_scan(hipcub)", hs);
-                size_t sb = scan_bytes;
-                PGX_HIP(hipcub::DeviceScan::ExclusiveSum(W.scan_tmp, sb, W.bi_cnt, W.bi_off, (int)(n_codes + 1), hs));
-            }
-            {
-                ProfScope prof(ctx, "index_scatter_kernel", hs);
-                index_scatter_kernel<<<hns, 256, 0, hs>>>(DS, hb0, hns, hnb, W.bi_off, W.bi_cnt, W.bi_ent);
-            }
-            LAUNCH_CHECK();
-            uint32_t first, count;
-            owned_reps(0, n_table, &first, &count);
-            if (count) {
-                ProfScope prof(ctx, "count_kernel<table>", hs);
-                auto kern = nt ? count_kernel<MODE_TABLE, true, 256> : count_kernel<MODE_TABLE, false, 256>;
-                // on the side stream leave room (LDS, wave slots) for the main stream's small kernels
-                // (past ~150k representatives the table pass is the longer stream of the two: it gets the machine;
-                //  measured on the 4000-genome shape, 8.2 s -> 7.6 s)
-                kern<<<std::min(count, hs == st || count > 150000u ? 4096u : side_grid), 256, 0, hs>>>(
-                    DS, d_rep_seq.as<uint32_t>(), nullptr, count, hb0, hns, hnb, W.bi_off, W.bi_ent, W.present,
-                    d_aan.as<int32_t>(), nullptr, nullptr, W.pairsA, W.nA, pair_cap,
-                    d_visits.as<unsigned long long>(), d_rcvis, nullptr, first, min_threshold(hb0, hnb), shard_count);
-                LAUNCH_CHECK();
-            }
-            return PGX_OK;
-        };
-        sweep_init_kernel<<<kBatchCap / 256, 256, 0, st>>>(d_counters.as<uint32_t>(), d_best, both ? d_rcvis : nullptr, d_done);
+        Pair *pairsW = d_pairsW.as<Pair>();
+        FilterArgs FA{};
+        FA.lines = d_lines.as<IndexLine>(); FA.pool = d_poolp; FA.newbits = d_newbits.as<uint32_t>();
+        FA.d_round_lo = dc + C_SEG0; FA.d_round_hi = dc + C_NEW; FA.epoch = 0;
+        FA.b0 = b0; FA.nbq = nb; FA.ns = ns; FA.shard_index = shard_index; FA.shard_count = shard_count;
+        FA.req_aan = d_aan.as<int32_t>(); FA.best = d_best; FA.done = d_done;
+        FA.pairs = pairsW; FA.n_pairs = dc + C_NW; FA.pair_cap = pair_cap;
+        FA.visits = d_visits.as<unsigned long long>(); FA.rc_visits = d_rcvis_p; FA.err = dc + C_ERR;
+
+        window_init_kernel<<<window_cap / 256, 256, 0, st>>>(dc, d_best, both ? d_rcvis_p : nullptr, d_done, window_cap);
         LAUNCH_CHECK();
-        const bool own_head_done = head_ready == b0;  // the previous sweep ran this sweep's head on the side stream
-        const uint32_t own_head_reps = head_reps;
-        // The next sweep's head runs on the side stream, overlapping this whole sweep: it depends on the
-        // representative list only (uploaded when the previous sweep closed). The event marks that
-        // point; the head itself is enqueued once this sweep's kernels up to the first block's
-        // results are in the queue, so the main stream never waits for the host to get to them.
-        const bool want_head = pipeline && b0 + sweep_cap < n;
-        if (want_head) PGX_HIP(hipEventRecord(ctx->ev_main, st));
-        uint32_t n_pre = 0;  // representatives the head has already been through
-        if (own_head_done) {
-            PGX_HIP(hipStreamWaitEvent(st, ctx->ev_side[parity], 0));
-            n_pre = own_head_reps;
-        } else {
-            int rc = sweep_head(B, b0, nb, ns, n_reps, st);
-            if (rc) return rc;
-            n_pre = n_reps;
-        }
-        uint32_t catch_first, catch_count;  // representatives created after the head was enqueued (the previous sweep's)
-        owned_reps(n_pre, n_reps, &catch_first, &catch_count);
-        if (catch_count) {
-            ProfScope prof(ctx, "count_kernel<table>", st);  // a few hundred entries: latency-bound, so wide
-            auto kern = nt ? count_kernel<MODE_TABLE, true, kCountWide> : count_kernel<MODE_TABLE, false, kCountWide>;
-            kern<<<std::min(catch_count, 4096u), kCountWide, 0, st>>>(
-                DS, d_rep_seq.as<uint32_t>(), nullptr, catch_count, b0, ns, nb, B.bi_off, B.bi_ent, B.present,
-                d_aan.as<int32_t>(), nullptr, nullptr, B.pairsA, B.nA, pair_cap, d_visits.as<unsigned long long>(),
-                d_rcvis, nullptr, catch_first, tmin, shard_count);
-            LAUNCH_CHECK();
-        }
         // diag + align of a selection of pair records, enqueued on the stream
-        auto evaluate = [&](const uint32_t *rep_map, Pair *pairs, const PairSel &sel, unsigned long long *best_arr,
-                            uint32_t key_flag, uint32_t grid_hint) -> int {
+        auto evaluate = [&](Pair *pairs, const PairSel &sel, unsigned long long *best_arr, uint32_t grid_hint) -> int {
             const uint32_t dg = grid_hint ? std::min(diag_grid, grid_hint) : diag_grid;
             const uint32_t ag = grid_hint ? std::min(align_grid, (grid_hint + 15) / 16) : align_grid;
             {
                 ProfScope prof(ctx, "diag_kernel", st);
-                diag_kernel<<<dg, 64, 0, st>>>(DS, rep_map, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
+                diag_kernel<<<dg, 64, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
                                                P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride);
             }
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "align_kernel", st);
-                align16_kernel<<<ag, 256, 0, st>>>(DS, rep_map, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0,
-                                                   best_arr, key_flag);
+                align16_kernel<<<ag, 256, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0,
+                                                   best_arr, 0u);
                 if (any_wide)
                     align_kernel<<<grid_hint ? std::min(align_grid, (grid_hint + 3) / 4) : align_grid, 256, 0, st>>>(
-                        DS, rep_map, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, key_flag, 1);
+                        DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, 1);
             }
             LAUNCH_CHECK();
             return PGX_OK;
         };
-        // phase A: against the representatives that exist already (fully on the device)
-        if (n_reps) {
-            const PairSel selA{nullptr, d_nA, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0};
-            int rc = evaluate(d_rep_seq.as<uint32_t>(), B.pairsA, selA, d_best, 0u, 0);
-            if (rc) return rc;
-        }
-        if (P->exchange) {
-            // table-sharded mode: fold the processes' partial winners of phase A (64-bit minima)
-            PGX_HIP(spin_sync(st));
-            if (P->exchange(P->exchange_user, d_best, kBatchCap) != 0) {
-                pgx_set_error("pgx_cluster_greedy: the exchange callback failed in the sweep at %u", b0);
+        // record-sharded mode: every process learns every member's best key (one all-gather per evaluation,
+        // enqueued on the stream by the caller's collective library; no host synchronisation)
+        auto exchange_best = [&]() -> int {
+            if (!P->exchange) return PGX_OK;
+            if (P->exchange(P->exchange_user, (void *)st) != 0) {
+                pgx_set_error("pgx_cluster_greedy: the exchange callback failed in the window at %u", b0);
                 return PGX_ERR_INTERNAL;
             }
-        }
-        bool head_enqueued = !want_head;
-        auto enqueue_head = [&]() -> int {
-            if (head_enqueued) return PGX_OK;
-            head_enqueued = true;
-            const uint32_t hb0 = b0 + sweep_cap, hnb = std::min(sweep_cap, n - hb0);
-            PGX_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_main, 0));
-            int rc = sweep_head(sbuf[parity ^ 1], hb0, hnb, hnb, n_reps, ctx->stream2);
-            if (rc) return rc;
-            PGX_HIP(hipEventRecord(ctx->ev_side[parity ^ 1], ctx->stream2));
-            head_ready = hb0; head_reps = n_reps;
+            min_rows_kernel<<<(nb + 255) / 256, 256, 0, st>>>(static_cast<const unsigned long long *>(P->exchange_recv),
+                                                              shard_count, PGX_EXCHANGE_KEYS, nb, d_best);
+            LAUNCH_CHECK();
             return PGX_OK;
         };
-        // phase B: members without a representative, one block at a time. A block is
-        // resolved exactly (all its in-block pairs are aligned, then the host walks it in
-        // order); every later query is then compared with the block's NEW representatives
-        // only, so pair work stays close to what the one-by-one pass would do.
-        uint32_t new_off = 0;  // new representatives of this sweep so far (staging offset)
-        // later queries against a list of new representatives
-        // (the list may live in page-locked host memory; its length comes from the device when
-        // `d_nr` is given, and the snapshot of the pair count was taken by the kernel before)
-        auto new_rep_pass = [&](const uint32_t *new_list, const uint32_t *d_nr, uint32_t nr) -> int {
-            {
-                ProfScope prof(ctx, "count_kernel<new>", st);
-                auto kern = nt ? count_kernel<MODE_NEW, true, kCountWide> : count_kernel<MODE_NEW, false, kCountWide>;
-                kern<<<d_nr ? 512u : nr, kCountWide, 0, st>>>(DS, new_list, d_nr, nr, b0, ns, nb, B.bi_off,
-                                         B.bi_ent, nullptr, d_aan.as<int32_t>(), d_best, d_done,
-                                         d_pairsN.as<Pair>(), d_nN, pair_cap,
-                                         count_replicated ? d_visits.as<unsigned long long>() : nullptr,
-                                         count_replicated ? d_rcvis : nullptr, nullptr, 0u, tmin, 1u);
-            }
-            LAUNCH_CHECK();
-            const PairSel selN{d_nN0, d_nN, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0};
-            return evaluate(nullptr, d_pairsN.as<Pair>(), selN, d_best, kNewBit, 0);
+        // the window's pairs found since the last round_begin: evaluated, winners folded into best[]
+        auto evaluate_round = [&]() -> int {
+            const PairSel sel{dc + C_EVAL0, dc + C_NW, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0};
+            int rc = evaluate(pairsW, sel, d_best, 0);
+            if (rc) return rc;
+            return exchange_best();
         };
-        // Discovery: still-unassigned members that cannot have an earlier unassigned candidate are
-        // certain new representatives (first_open_kernel / certain_kernel). They are confirmed in
-        // one step, and the pass against them assigns most of the remaining members before any
-        // block is formed.
-        {
-            list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_blk_list.as<uint32_t>(),
-                                                               d_blk);  // d_blk[0] = open members: zero since the sweep began
-            LAUNCH_CHECK();
-            const uint32_t epoch = 1u + (uint32_t)((S.sweeps - 1) % 0xFFFFFu);
-            if (epoch == 1u) PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)n_codes * 4, st));
+        // phase A: against the representatives that exist already
+        if (n_reps) {
             {
-                ProfScope prof(ctx, "discover_kernels", st);
-                first_open_kernel<<<(nb + 3) / 4, 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), d_blk, b0, epoch,
-                                                                d_first.as<uint32_t>());
-                certain_kernel<<<(nb + 3) / 4, 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), d_blk, b0, both ? 1u : 0u,
-                                                             epoch, d_first.as<uint32_t>(), d_aan.as<int32_t>(), d_done,
-                                                             d_new_list.as<uint32_t>(), d_ncertain, d_nN, d_nN0);
+                ProfScope prof(ctx, "filter_kernel<all>", st);
+                auto kern = nt ? filter_kernel<true, false> : filter_kernel<false, false>;
+                kern<<<std::min(filter_grid, (ns + 3) / 4), 256, 0, st>>>(DS, FA);
             }
             LAUNCH_CHECK();
-            // no round trip: the pass takes the list and its length from the device; the host
-            // learns both with the first block's results
-            int rc = new_rep_pass(d_new_list.as<uint32_t>(), d_ncertain, 0);
+            filter_walk_words += window_words * (both ? 2 : 1);
+            int rc = evaluate_round();
             if (rc) return rc;
         }
-        bool first_block = true;
-        for (;;) {
-            select_block_kernel<<<1, 1024, 0, st>>>(d_best, d_done, d_inblk, b0, nb, kBlockCap,
-                                                    d_blk_list.as<uint32_t>(), d_blk, d_nK,
-                                                    reinterpret_cast<unsigned long long *>(d_hascand));  // + has_cand, accepted = 0
+        // append list[C_SEG0, C_NEW) to the index and compare every later window member with the new entries
+        auto append_and_filter = [&]() -> int {
+            ++epoch_idx;
+            PGX_HIP(hipMemsetAsync(d_newbits.p, 0, ((size_t)n_codes / 32 + 2) * 4, st));
+            {
+                ProfScope prof(ctx, "index_append", st);
+                index_count_kernel<<<512, 256, 0, st>>>(DS, d_new_list.as<uint32_t>(), dc + C_SEG0, dc + C_NEW,
+                                                        d_lines.as<IndexLine>(), d_touched.as<uint32_t>(), dc + C_TOUCH,
+                                                        (uint32_t)max_window_words, dc + C_ERR);
+                index_grow_kernel<<<512, 256, 0, st>>>(d_lines.as<IndexLine>(), d_poolp, d_idx.as<uint32_t>(),
+                                                       (uint32_t)pool_cap, d_touched.as<uint32_t>(), dc + C_TOUCH,
+                                                       (uint32_t)max_window_words, epoch_idx, d_newbits.as<uint32_t>(),
+                                                       dc + C_ERR);
+                index_write_kernel<<<512, 256, 0, st>>>(DS, d_new_list.as<uint32_t>(), dc + C_SEG0, dc + C_NEW,
+                                                        d_lines.as<IndexLine>(), d_poolp);
+            }
+            LAUNCH_CHECK();
+            FA.epoch = epoch_idx;
+            {
+                ProfScope prof(ctx, "filter_kernel<new>", st);
+                auto kern = nt ? filter_kernel<true, true> : filter_kernel<false, true>;
+                kern<<<std::min(filter_grid, (ns + 3) / 4), 256, 0, st>>>(DS, FA);
+            }
+            LAUNCH_CHECK();
+            return evaluate_round();
+        };
+        // Discovery rounds: still-open members that cannot have an earlier open candidate are certain new
+        // representatives (first_open_kernel / certain_kernel). They are confirmed at once, appended to the
+        // index, and the pass against them assigns most of the remaining members; a second round confirms
+        // the members the first round's representatives rejected (the outliers of their families). All on
+        // the device: the host learns the outcome with the first block's results.
+        for (int round = 0; round < kDiscoveryRounds; ++round) {
+            if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)n_codes * 4, st)); epoch_tag = 1; }
+            round_begin_kernel<<<1, 1, 0, st>>>(dc);
+            list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN);
             LAUNCH_CHECK();
             {
-                ProfScope prof(ctx, "count_kernel<block>", st);
-                auto kern = nt ? count_kernel<MODE_BLOCK, true, kCountWide> : count_kernel<MODE_BLOCK, false, kCountWide>;
-                kern<<<kBlockCap, kCountWide, 0, st>>>(
-                    DS, d_blk_list.as<uint32_t>(), d_blk, 0, b0, ns, nb, B.bi_off, B.bi_ent, nullptr,
-                    d_aan.as<int32_t>(), nullptr, d_inblk, d_pairsK.as<Pair>(), d_nK, pair_cap_k, nullptr, d_rcvis,
-                    d_hascand, 0u, tmin, 1u);
+                ProfScope prof(ctx, "discover_kernels", st);
+                first_open_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
+                                                                                 epoch_tag, d_first.as<uint32_t>());
+                certain_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
+                                                                              both ? 1u : 0u, epoch_tag, d_first.as<uint32_t>(),
+                                                                              d_aan.as<int32_t>(), d_done, d_new_list.as<uint32_t>(),
+                                                                              dc + C_NEW);
+            }
+            LAUNCH_CHECK();
+            filter_walk_words += window_words * (both ? 2 : 1);
+            int rc = append_and_filter();
+            if (rc) return rc;
+        }
+        // Blocks: members still without a representative, <= kBlockCap at a time, in order. A block is
+        // resolved exactly (all its in-block pairs are found and evaluated, then the host walks it in
+        // order); every later member is then compared with the block's NEW representatives only, so
+        // pair work stays close to what the one-by-one pass would do.
+        bool first_block = true;
+        uint32_t n_listed = 0;   // entries of the window's new-representative list the host has seen
+        for (;;) {
+            select_block_kernel<<<1, kSelThreads, 0, st>>>(d_best, d_done, d_inblk, b0, nb, kBlockCap,
+                                                           d_blk_list.as<uint32_t>(), dc + C_BLK, dc + C_NK,
+                                                           d_hascand, window_cap);  // + has_cand, accepted = 0
+            LAUNCH_CHECK();
+            {
+                ProfScope prof(ctx, "block_pairs_kernel", st);
+                block_pairs_kernel<<<2048, 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), dc + C_BLK, b0, both ? 1u : 0u,
+                                                         d_aan.as<int32_t>(), d_pairsK.as<Pair>(), dc + C_NK, pair_cap_k,
+                                                         d_hascand);
             }
             LAUNCH_CHECK();
             // A block member without an earlier in-block candidate (has_cand clear) is certainly a
@@ -1931,43 +2032,46 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             // pairs against those follow. Whatever the in-order walk on the host still needs
             // afterwards goes through follow-up rounds.
             {
-                const PairSel selK{nullptr, d_nK, pair_cap_k, nullptr, 0, nullptr, d_hascand, d_accepted, b0, 0};
-                int rc = evaluate(nullptr, d_pairsK.as<Pair>(), selK, nullptr, 0u, 0);
+                const PairSel selK{nullptr, dc + C_NK, pair_cap_k, nullptr, 0, nullptr, d_hascand, d_accepted, b0, 0};
+                int rc = evaluate(d_pairsK.as<Pair>(), selK, nullptr, 0);
                 if (rc) return rc;
-                const PairSel selK2{nullptr, d_nK, pair_cap_k, nullptr, 0, d_hascand, d_accepted, nullptr, b0, 1};
-                rc = evaluate(nullptr, d_pairsK.as<Pair>(), selK2, nullptr, 0u, 0);
+                const PairSel selK2{nullptr, dc + C_NK, pair_cap_k, nullptr, 0, d_hascand, d_accepted, nullptr, b0, 1};
+                rc = evaluate(d_pairsK.as<Pair>(), selK2, nullptr, 0);
                 if (rc) return rc;
             }
-            // one round trip: counters, the block list, the in-block pairs (and, the first time,
-            // the certain representatives), written to host memory by one kernel
+            // one round trip: counters, the block list, the in-block pairs (and the representatives the
+            // discovery rounds confirmed), written to host memory by one kernel
             {
                 PubArgs pa{};
-                pa.seg[0] = {d_counters.as<uint32_t>(), h_cnt.p, nullptr, 8, 1, 8};
-                pa.seg[1] = {d_blk_list.as<uint32_t>(), h_blk.p, d_blk, 0, 1, kBlockCap};
-                pa.seg[2] = {d_pairsK.as<uint32_t>(), reinterpret_cast<uint32_t *>(hK.p), d_nK, 0, kPairWords, pair_cap_k};
+                pa.seg[0] = {dc, h_cnt.p, nullptr, C_COUNT, 1, C_COUNT};
+                pa.seg[1] = {d_blk_list.as<uint32_t>(), h_blk.p, dc + C_BLK, 0, 1, kBlockCap};
+                pa.seg[2] = {d_pairsK.as<uint32_t>(), reinterpret_cast<uint32_t *>(hK.p), dc + C_NK, 0, kPairWords, pair_cap_k};
                 pa.n = 3;
-                if (first_block) pa.seg[pa.n++] = {d_new_list.as<uint32_t>(), h_new.p, d_ncertain, 0, 1, kBatchCap};
+                if (first_block) pa.seg[pa.n++] = {d_new_list.as<uint32_t>(), h_new.p, dc + C_NEW, 0, 1, window_cap};
                 publish_kernel<<<64, 256, 0, st>>>(pa);
                 LAUNCH_CHECK();
             }
             if (first_block) {
-                { int rc = enqueue_head(); if (rc) return rc; }
-                // everything up to here was enqueued without looking at results: the previous sweep's
+                // everything up to here was enqueued without looking at results: the previous window's
                 // bookkeeping runs now, behind that work, and only then is the member state reset
                 if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
                 for (uint32_t q = 0; q < nb; ++q) status[q] = ST_OPEN;
             }
             PGX_HIP(spin_sync(st));
+            if (h_cnt.p[C_ERR]) {
+                pgx_set_error("pgx_cluster_greedy: word index failure %u in the window at %u (1 = touched list, 2 = overflow "
+                              "pool, 3 = exact table)", h_cnt.p[C_ERR], b0);
+                return PGX_ERR_CAPACITY;
+            }
             if (first_block) {
-                const uint32_t n_certain = h_cnt.p[6];
-                for (uint32_t i = 0; i < n_certain; ++i) status[h_new.p[i] - b0] = ST_REP;
-                new_off = n_certain;
+                n_listed = h_cnt.p[C_NEW];
+                for (uint32_t i = 0; i < n_listed; ++i) status[h_new.p[i] - b0] = ST_REP;
                 first_block = false;
             }
-            const uint32_t n_blk = h_cnt.p[4], n_open = h_cnt.p[5], nK = h_cnt.p[2];
-            if (h_cnt.p[1] > pair_cap || nK > pair_cap_k) {
-                pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u) in sweep at %u",
-                              h_cnt.p[1], nK, b0);
+            const uint32_t n_blk = h_cnt.p[C_BLK], n_open = h_cnt.p[C_OPEN], nK = h_cnt.p[C_NK];
+            if (h_cnt.p[C_NW] > pair_cap || nK > pair_cap_k) {
+                pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u) in the window at %u",
+                              h_cnt.p[C_NW], nK, b0);
                 return PGX_ERR_CAPACITY;
             }
             if (n_blk == 0) break;
@@ -2007,7 +2111,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                             return PGX_ERR_CAPACITY;
                         }
                         if (!(pr.flags & F_ACCEPT)) continue;
-                        const unsigned long long key = pair_key(pr, true);
+                        const unsigned long long key = pair_key(pr);
                         if (su == ST_REP) { if (key < win) { win = key; win_iden = pr.iden; } }
                         else if (key < open_acc) open_acc = key;  // wins if that member turns out a representative
                     }
@@ -2015,11 +2119,11 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                     for (uint32_t e = lo; e < hi; ++e) {
                         const Pair &pr = hK.p[order_k[e]];
                         if (status[pr.r - b0] == ST_MEMBER || (pr.flags & F_EVAL)) continue;
-                        if (pair_key(pr, true) < win) { flight.push_back(order_k[e]); needs = true; }
+                        if (pair_key(pr) < win) { flight.push_back(order_k[e]); needs = true; }
                     }
                     if (needs || open_acc < win) { any_open = true; continue; }
                     if (win != kNoBest) {
-                        status[q] = ST_MEMBER; member_of[q] = (uint32_t)win & ~kNewBit; won_new[q] = 1;
+                        status[q] = ST_MEMBER;
                         winner_key[q] = win; iden_of[k] = win_iden; strand_of[k] = (uint8_t)(win >> 63);
                     } else {
                         status[q] = ST_REP;
@@ -2035,7 +2139,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 PGX_HIP(hipMemcpyAsync(d_list.p, h_list.p, (size_t)nl * 4, hipMemcpyHostToDevice, st));
                 {
                     const PairSel selL{nullptr, nullptr, 0, d_list.as<uint32_t>(), nl, nullptr, nullptr, nullptr, b0, 0};
-                    int rc = evaluate(nullptr, d_pairsK.as<Pair>(), selL, nullptr, 0u, nl);
+                    int rc = evaluate(d_pairsK.as<Pair>(), selL, nullptr, nl);
                     if (rc) return rc;
                 }
                 gather_pairs_kernel<<<(nl + 255) / 256, 256, 0, st>>>(d_pairsK.as<Pair>(), d_list.as<uint32_t>(), nl,
@@ -2054,7 +2158,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 for (uint32_t e = bucket_k[t]; e < bucket_k[t + 1]; ++e) {
                     const Pair &pr = hK.p[order_k[e]];
                     if (status[pr.r - b0] != ST_REP) continue;
-                    if (pair_key(pr, true) > win) continue;
+                    if (pair_key(pr) > win) continue;
                     if (!count_replicated) continue;
                     S.filter_pairs++;
                     if ((pr.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
@@ -2064,48 +2168,52 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                     }
                 }
             }
-            if (count_replicated) account(hK.p, nK, false);
+            if (count_replicated) account(hK.p, nK);
             t_resolve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count();
-            // later queries against the block's new representatives (on the device)
+            // later members against the block's new representatives (on the device)
             if (!new_reps.empty()) {
                 const uint32_t nr = (uint32_t)new_reps.size();
-                // the list stays in page-locked host memory (the pass reads each entry once); every
-                // block has its own range, so nothing in flight is overwritten
-                uint32_t *list = h_new.p + new_off;
+                // the list is read from page-locked host memory; every block has its own range, so nothing
+                // in flight is overwritten
+                uint32_t *list = h_push.p + n_listed;
                 std::copy(new_reps.begin(), new_reps.end(), list);
-                new_off += nr;
-                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, d_nN, d_nN0);
-                int rc = new_rep_pass(list, nullptr, nr);
+                n_listed += nr;
+                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb);
+                round_begin_kernel<<<1, 1, 0, st>>>(dc);
+                push_list_kernel<<<(nr + 255) / 256, 256, 0, st>>>(list, nr, d_new_list.as<uint32_t>(), dc);
+                push_done_kernel<<<1, 1, 0, st>>>(nr, dc);
+                LAUNCH_CHECK();
+                filter_walk_words += window_words * (both ? 2 : 1);
+                int rc = append_and_filter();
                 if (rc) return rc;
             }
             if (n_open == n_blk) break;  // that was the last block
         }
-        // ---- close the sweep ---------------------------------------------------------------
+        // ---- close the window ---------------------------------------------------------------
         {   // counters, winners, and exactly the pair records that exist, in one launch
             PubArgs pa{};
-            pa.seg[0] = {d_counters.as<uint32_t>(), h_cnt.p, nullptr, 8, 1, 8};
+            pa.seg[0] = {dc, h_cnt.p, nullptr, C_COUNT, 1, C_COUNT};
             pa.seg[1] = {reinterpret_cast<const uint32_t *>(d_best), reinterpret_cast<uint32_t *>(h_best.p), nullptr, nb, 2, nb};
-            pa.seg[2] = {d_nA, h_nA.p, nullptr, 1, 1, 1};
-            pa.seg[3] = {reinterpret_cast<const uint32_t *>(B.pairsA), reinterpret_cast<uint32_t *>(hA.p), d_nA, 0, kPairWords,
-                         (uint32_t)std::min<size_t>(hA.cap, pair_cap)};
-            pa.seg[4] = {d_pairsN.as<uint32_t>(), reinterpret_cast<uint32_t *>(hN.p), d_nN, 0, kPairWords,
-                         (uint32_t)std::min<size_t>(hN.cap, pair_cap)};
-            pa.n = 5;
-            if (both) pa.seg[pa.n++] = {reinterpret_cast<const uint32_t *>(d_rcvis), reinterpret_cast<uint32_t *>(h_rcvis.p), nullptr, nb, 2, nb};
+            pa.seg[2] = {reinterpret_cast<const uint32_t *>(pairsW), reinterpret_cast<uint32_t *>(hW.p), dc + C_NW, 0, kPairWords,
+                         (uint32_t)std::min<size_t>(hW.cap, pair_cap)};
+            pa.n = 3;
+            if (both) pa.seg[pa.n++] = {reinterpret_cast<const uint32_t *>(d_rcvis_p), reinterpret_cast<uint32_t *>(h_rcvis.p), nullptr, nb, 2, nb};
             publish_kernel<<<64, 256, 0, st>>>(pa);
             LAUNCH_CHECK();
         }
         PGX_HIP(spin_sync(st));
-        const uint32_t nA = h_nA.p[0], nN = h_cnt.p[1];
-        if (nA > pair_cap || nN > pair_cap) {
-            pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u > %u) in sweep at %u",
-                          nA, nN, pair_cap, b0);
+        const uint32_t nW = h_cnt.p[C_NW];
+        if (h_cnt.p[C_ERR]) {
+            pgx_set_error("pgx_cluster_greedy: word index failure %u in the window at %u", h_cnt.p[C_ERR], b0);
             return PGX_ERR_CAPACITY;
         }
-        if (nA > hA.cap || nN > hN.cap) {  // the host buffers were too small: grow them and fetch again
-            PGX_HIP(hA.reserve(nA)); PGX_HIP(hN.reserve(nN));  // (reserve keeps nothing: copy whole ranges again)
-            if (nA) PGX_HIP(hipMemcpyAsync(hA.p, B.pairsA, (size_t)nA * sizeof(Pair), hipMemcpyDeviceToHost, st));
-            if (nN) PGX_HIP(hipMemcpyAsync(hN.p, d_pairsN.p, (size_t)nN * sizeof(Pair), hipMemcpyDeviceToHost, st));
+        if (nW > pair_cap) {
+            pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u > %u) in the window at %u", nW, pair_cap, b0);
+            return PGX_ERR_CAPACITY;
+        }
+        if (nW > hW.cap) {  // the host buffer was too small: grow it and fetch again
+            PGX_HIP(hW.reserve(nW));  // (reserve keeps nothing: copy the whole range again)
+            PGX_HIP(hipMemcpyAsync(hW.p, pairsW, (size_t)nW * sizeof(Pair), hipMemcpyDeviceToHost, st));
             PGX_HIP(spin_sync(st));
         }
         // members that were never in a block: their winner is the 64-bit minimum in best[]
@@ -2116,8 +2224,6 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             if (key == kNoBest) { pgx_set_error("pgx_cluster_greedy: unresolved member after the last block"); return PGX_ERR_INTERNAL; }
             status[q] = ST_MEMBER;
             winner_key[q] = key;
-            won_new[q] = ((uint32_t)key & kNewBit) != 0;
-            member_of[q] = (uint32_t)key & ~kNewBit;
             strand_of[b0 + q] = (uint8_t)(key >> 63);
         }
         if (both)  // reverse-strand word walks happen only for queries the forward strand did not place
@@ -2130,37 +2236,32 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 rep_seq.push_back(b0 + q);
                 S.sum_len_reps += h_len[b0 + q];
                 S.rep_words += h_wcnt[b0 + q];
-                if ((rep_seq.size() - 1) % shard_count == shard_index) own_rep_words += h_wcnt[b0 + q];
             }
         for (uint32_t q = 0; q < nb; ++q)
-            if (status[q] == ST_MEMBER)
-                cluster_of[b0 + q] = won_new[q] ? cluster_of[member_of[q]] : (int32_t)member_of[q];
+            if (status[q] == ST_MEMBER) cluster_of[b0 + q] = cluster_of[(uint32_t)winner_key[q] & 0x7FFFFFFFu];
         // identities of the winners + the candidates the one-by-one pass would have examined: pure
-        // bookkeeping on the host copies, deferred until the next sweep's first kernels are enqueued
+        // bookkeeping on the host copies, deferred until the next window's first kernels are enqueued
         {
-            const Pair *pA = hA.p, *pN = hN.p;
-            deferred = [&, b0, nA, nN, pA, pN]() -> int {
-                auto examine = [&](const Pair &p, bool is_new, uint32_t len2, bool counted) {
+            const Pair *pW = hW.p;
+            deferred = [&, b0, nW, pW]() -> int {
+                account(pW, nW);
+                bool fits = true;
+                for (uint32_t i = 0; i < nW; ++i) {
+                    const Pair &p = pW[i];
                     const uint32_t k = real(p.q), q = k - b0;
-                    if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) return false;
-                    const unsigned long long key = pair_key(p, is_new);
+                    if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) { fits = false; continue; }
+                    const unsigned long long key = pair_key(p);
                     // the one-by-one pass examines candidates in key order up to and including the winner
                     if (status[q] == ST_REP || key <= winner_key[q]) {
-                        if (counted) S.filter_pairs++;
-                        if (counted && (p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
+                        S.filter_pairs++;
+                        if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
                             S.aligned_pairs++;
-                            S.aligned_rep_len += len2;
+                            S.aligned_rep_len += h_len[p.r];
                             S.dp_cells += (uint64_t)h_len[k] * (uint64_t)(p.band_right - p.band_left + 1);
                         }
                         if ((p.flags & F_ACCEPT) && status[q] == ST_MEMBER && key == winner_key[q]) iden_of[k] = p.iden;
                     }
-                    return true;
-                };
-                account(pA, nA, true);
-                if (count_replicated) account(pN, nN, false);
-                bool fits = true;
-                for (uint32_t i = 0; i < nA; ++i) fits &= examine(pA[i], false, h_len[rep_seq[pA[i].r]], true);
-                for (uint32_t i = 0; i < nN; ++i) fits &= examine(pN[i], true, h_len[pN[i].r], count_replicated);
+                }
                 if (!fits) {
                     pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
                     return PGX_ERR_CAPACITY;
@@ -2168,23 +2269,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 return PGX_OK;
             };
         }
-        if (rep_seq.size() > n_reps) {
-            // staged through a pinned buffer of its own parity so the next sweep can start at once
-            uint32_t *stage = h_rep_stage[S.sweeps & 1].p;
-            std::copy(rep_seq.begin() + n_reps, rep_seq.end(), stage);
-            PGX_HIP(hipMemcpyAsync(d_rep_seq.as<uint32_t>() + n_reps, stage, (rep_seq.size() - n_reps) * 4,
-                                   hipMemcpyHostToDevice, st));
-        }
         t_close += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
         if (trace && std::getenv("PGX_TRACE")[0] == '2')
-            fprintf(stderr, "[pgx] sweep %4llu b0 %8u len %5u..%5u blocks %2llu reps +%5zu (total %7zu) pairsA %7u pairsN %7u  %.2f ms\n",
+            fprintf(stderr, "[pgx] window %4llu b0 %8u len %5u..%5u blocks %2llu reps +%5zu (total %7zu) pairs %7u  %.2f ms\n",
                     (unsigned long long)S.sweeps, b0, h_len[b0], h_len[b0 + nb - 1],
-                    (unsigned long long)(n_blocks - blocks_before), rep_seq.size() - n_reps, rep_seq.size(), nA, nN,
+                    (unsigned long long)(n_blocks - blocks_before), rep_seq.size() - n_reps, rep_seq.size(), nW,
                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sweep0).count());
     }
     if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
     if (trace)
-        fprintf(stderr, "[pgx] sweeps %llu blocks %llu (+%llu follow-up rounds): loop %.1f ms = wait %.1f + block resolve %.1f + sweep close %.1f + "
+        fprintf(stderr, "[pgx] windows %llu blocks %llu (+%llu follow-up rounds): loop %.1f ms = wait %.1f + block resolve %.1f + window close %.1f + "
                 "enqueue/other %.1f\n", (unsigned long long)S.sweeps, (unsigned long long)n_blocks, (unsigned long long)n_rounds,
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count(), 1e3 * g_wait_s,
                 1e3 * t_resolve, 1e3 * t_close,
@@ -2194,13 +2288,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     unsigned long long visits_table = 0;
     PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
-    PGX_HIP(hipStreamSynchronize(ctx->stream2));  // idle by now; lets the runtime retire the side stream's commands here
     S.posting_visits = visits_table + visits_rc;
     S.reserved[0] = gpu_pairs; S.reserved[1] = gpu_aligned; S.reserved[2] = gpu_aligned_bytes;
-    S.reserved[3] = table_stream_words;
+    S.reserved[3] = filter_walk_words;
     S.n_clusters = rep_seq.size();
 
-    phase("sweep loop");
+    phase("window loop");
     // ---- outputs in the caller's order; member numbers follow the sorted order (A.3) ------
     std::vector<uint32_t> members(rep_seq.size(), 0);
     for (uint32_t k = 0; k < n; ++k) {
@@ -2209,7 +2302,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         out_cluster[o] = c;
         out_member[o] = (int32_t)members[c]++;
         out_identity[o] = iden_of[k] >= 0 ? (float)iden_of[k] / (float)h_len[k] : 0.f;
-        if (out_strand) out_strand[o] = iden_of[k] >= 0 ? strand_of[k] : 0;
+        if (out_strand) out_strand[o] = strand_of[k];   // (set for members only)
     }
     phase("outputs");
     if (out_n_clusters) *out_n_clusters = (uint32_t)rep_seq.size();
@@ -2227,6 +2320,8 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     for (uint32_t i = 0; i < n_in; ++i) PGX_REQUIRE(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing");
     const uint64_t total_in = n_in ? offsets[n_in] : 0;
     DevBuf d_res, d_off;
+    d_res.ctx = ctx; d_res.slot = 70;      // the upload buffers live in the context's workspace too
+    d_off.ctx = ctx; d_off.slot = 71;
     PGX_HIP(d_res.alloc(total_in + 16));
     PGX_HIP(d_off.alloc(((size_t)n_in + 1) * 8));
     if (n_in) {

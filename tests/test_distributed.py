@@ -1,6 +1,7 @@
-"""Multi-process path: pan/core iterations are sharded over ranks with no
-data-path collective; the shares are all-gathered. Rehearsed here with 2 (and 3) gloo ranks
-on CPU, the oracle standing in for the kernel; on GPUs the same code runs over RCCL."""
+"""Multi-process paths, rehearsed with 2 and 3 gloo ranks on CPU, the oracle standing in
+for the kernels; on GPUs the same host code runs over RCCL. Pan/core: iterations sharded, no data-path
+collective, shares all-gathered. Clustering: records sharded, best keys all-gathered between the steps
+of a window (tests/sharded_model.py restates the protocol the HIP library runs)."""
 import os
 import sys
 
@@ -57,26 +58,42 @@ def test_shard_bounds_cover_everything():
             assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
 
 
-# ---- clustering, table-sharded mode: the exchange callback and the result merge over gloo ----------
+# ---- clustering, record-sharded mode: the partition protocol over real collectives ----------
+def _model_inputs():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_cluster_oracle import mutate, params, rand_seq
+    rng = np.random.default_rng(3)
+    fams = [rand_seq(rng, int(n)) for n in rng.integers(40, 200, 14)]
+    seqs = [mutate(rng, fams[i % 14], int(rng.integers(0, len(fams[i % 14]) * 0.3))) for i in range(120)]
+    return seqs + ['MKV', 'ACDEFGHIKLM'], params()
+
+
 def _cluster_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     import torch
+    import oracle
+    import sharded_model
     from pangenomix_amd import cluster
-    # unsigned keys as the library builds them: strand << 63 | minc << 32 | new << 31 | index; ~0 = none
-    rng = np.random.default_rng(100 + rank)
-    keys_u = rng.integers(0, 2 ** 64, size=cluster.EXCHANGE_KEYS, dtype=np.uint64)
-    keys_u[rank::7] = np.uint64(2 ** 64 - 1)                     # "no candidate on this rank"
-    keys_u[5] = np.uint64(2 ** 63 + rank)                        # top bit set on every rank
-    keys = torch.from_numpy(keys_u.view(np.int64).copy())
-    p = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
-    sp, keep = cluster.shard_params(p, rank, world, keys,
-                                    lambda t: dist.all_reduce(t, op=dist.ReduceOp.MIN))
+    from test_cluster_oracle import pack
+    seqs, p = _model_inputs()
+    # (1) the window protocol with this rank evaluating only its own members; the exchange is the
+    #     product's all-gather wrapper over the gloo group, the fold and the partition rule are the product's
+    got, evaluated = sharded_model.run(seqs, p, oracle, pack, rank, world, cluster.group_all_gather(dist.group.WORLD),
+                                       cluster.fold_best_keys, cluster.owner_of, window=16)
+    # (2) the C-ABI callback as the library calls it: enqueue-only all-gather of the send buffer
+    send = torch.full((cluster.EXCHANGE_KEYS,), -1, dtype=torch.int64)
+    send[rank::world] = 1000 + rank                                   # this rank's members
+    send[7] = -(2 ** 63) + rank                                       # top bit set: unsigned order matters
+    recv = torch.zeros((world, cluster.EXCHANGE_KEYS), dtype=torch.int64)
+    sp, keep = cluster.shard_params(p, rank, world, send, recv, cluster.group_all_gather(dist.group.WORLD))
     assert (sp.shard_index, sp.shard_count) == (rank, world) and sp.identity == p.identity
-    rc = sp.exchange(None, None, cluster.EXCHANGE_KEYS)          # what libpgx calls once per sweep
-    assert rc == 0
+    assert sp.exchange(None, None) == 0
+    folded = cluster.fold_best_keys(recv.numpy())
 
+    # (3) the fold of the per-rank partial outputs
     def host_reduce(op):
         def f(a):
             t = torch.from_numpy(np.ascontiguousarray(a).astype(np.int64 if a.dtype != np.float32 else np.float32))
@@ -85,30 +102,37 @@ def _cluster_worker(rank, world, port, out_dir):
         return f
     n = 10
     ident = np.zeros(n, dtype=np.float32); ident[rank::world] = 0.8 + 0.01 * rank   # known to one rank each
-    strand = np.zeros(n, dtype=np.uint8); strand[rank] = 1
     stats = {k: 10 * (rank + 1) for k in cluster.PARTIAL_STATS}
-    stats.update(n_input=n, n_clusters=3, gpu={'pairs': rank + 1, 'aligned': 1, 'aligned_bytes': 2, 'table_stream_words': 5})
-    merged = cluster.merge_shard_results((np.arange(n), np.arange(n), ident, strand, 3, stats),
+    stats.update(n_input=n, n_clusters=3, gpu={k: rank + 1 for k in cluster.GPU_STATS})
+    merged = cluster.merge_shard_results((np.arange(n), np.arange(n), ident, np.zeros(n, np.uint8), 3, stats),
                                          host_reduce(dist.ReduceOp.SUM), host_reduce(dist.ReduceOp.MAX))
-    np.savez(os.path.join(out_dir, 'c%d.npz' % rank), before=keys_u, after=keys.numpy().view(np.uint64),
-             ident=merged[2], strand=merged[3],
+    np.savez(os.path.join(out_dir, 'c%d.npz' % rank), clusters=got, evaluated=evaluated, folded=folded,
+             ident=merged[2],
              stats=np.array([merged[5][k] for k in cluster.PARTIAL_STATS] + [merged[5]['gpu']['pairs'], merged[5]['n_input']]))
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('world', [2, 3])
-def test_cluster_exchange_and_merge_over_gloo(world, tmp_path):
+def test_record_sharded_protocol_over_gloo(world, tmp_path):
     port = 31500 + os.getpid() % 2000 + world
     mp.spawn(_cluster_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     outs = [np.load(str(tmp_path / ('c%d.npz' % r))) for r in range(world)]
-    want = np.minimum.reduce([o['before'] for o in outs])        # unsigned minimum
-    assert want[5] == np.uint64(2 ** 63)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import oracle
+    from test_cluster_oracle import pack
+    seqs, p = _model_inputs()
+    res, off = pack(seqs)
+    want = oracle.cluster_greedy(res, off, p)
+    evaluated = [int(o['evaluated']) for o in outs]
     for o in outs:
-        assert np.array_equal(o['after'], want)
+        assert np.array_equal(o['clusters'], want[0])             # every rank: the sequential result
+        # the gathered keys folded by unsigned minimum: each member's key comes from its owner
+        f = o['folded']
+        assert all(int(f[i]) == 1000 + i % world for i in range(20) if i != 7) and int(f[7]) == 2 ** 63
         assert np.array_equal(o['ident'], outs[0]['ident']) and (o['ident'] > 0.79).all()
-        assert o['strand'][:world].tolist() == [1] * world
         tri = 10 * world * (world + 1) // 2
         assert o['stats'].tolist() == [tri] * 5 + [world * (world + 1) // 2, 10]   # partial counters add, replicated stay
+    assert max(evaluated) < 0.8 * sum(evaluated)                  # the pair work really was split over the ranks
 
 
 # ---- rank 0 drives the reference-style entry point, the other ranks serve its clustering calls -----
