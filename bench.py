@@ -1,24 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the pangenomix hot path on MI355X.
 
-One "step" = one pass of the hot path over the 400-genome workload (BASELINE.json
-configs[2]; the Bacteroides files are not available offline, so the deterministic synthetic
-stand-in `cfg-3s` of SURVEY.md §8d is used: 400 genomes x 4,500 CDS):
-  (a) K1  greedy clustering at 0.8 identity of the non-redundant protein set  -> proteins/s
-  (b) K3  1000 pan/core rarefaction iterations on a 150,000 x 400 presence matrix -> iters/s
-with the inputs resident in HBM when the timed region starts.
+One "step" = one pass of the hot path over one workload, inputs resident in HBM when the timed
+region starts:
+  (a) K1  greedy clustering at 0.8 identity of the non-redundant protein set  -> proteins/s  (M1)
+  (b) K3  1000 pan/core rarefaction iterations on a 150,000 x 400 presence matrix -> iters/s (M2)
 
-  python bench.py [--gpus N --steps K --warmup W] [--workload cfg-3s|cfg-2s|small|tiny]
+  python bench.py [--gpus N --steps K --warmup W] [--workload cfg-3s|cfg-4|cfg-2s|small|tiny]
 
-`value` is proteins/s of (a) (N_nr sequences handed to the clustering call / its time);
-(b) is reported under "pan_core". N > 1 is launched by torch.distributed.run, one rank per
-GPU (RCCL): every rank runs the same work on its own copy (independent units, no data-path
-collective), times are max-reduced and `value` is the aggregate -> "weak" scaling.
+N = 1: the 400-genome workload the metric is quoted on (BASELINE.json configs[2]; the Bacteroides
+files are not available offline, so the deterministic synthetic stand-in `cfg-3s` of SURVEY.md 8d:
+400 genomes x 4,500 CDS). N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL):
+ONE clustering job of the 4000-genome shape `cfg-4` (configs[3]) split over the ranks by record --
+window member i is filtered and aligned by rank i % N, best keys all-gathered over xGMI -- and the
+pan/core iterations split by iteration: "strong" scaling. `--shard replicas` (explicit) runs N
+independent copies instead.
+
+`value` is proteins/s of (a): sequences handed to the clustering call / its time. Beside the timed
+steps, rank 0 measures once each (reported, never part of `value`): the host-pointer entry point
+(H2D included), M2 through estimate_pan_core_size() (permutations, upload, DataFrame included), the
+end-to-end build_cds_pangenome() wall time, and the CPU oracle on a bounded sample.
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,34 +34,40 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # gfx950 spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0   # gfx950 spec, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0   # aggregate L2, same guide
+PMC_SUMMARY = os.path.join('profiles', 'r02_pmc_summary_cfg3s.json')
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cluster_algorithmic_bytes(st, bits=5):
-    """B_cluster of SURVEY §8d from the sequential-rule counters (b = 5 bits per residue, the
+def cluster_terms(st, bits=5):
+    """The terms of B_cluster from the sequential-rule counters (b = 5 bits per residue, the
     packed layout the alignment kernel reads)."""
     b = bits
-    return ((b * st['sum_len_queries'] + 7) // 8 + 4 * st['posting_visits'] + (b * st['aligned_rep_len'] + 7) // 8
-            + (b * st['sum_len_reps'] + 7) // 8 + 4 * st['rep_words'] + 12 * st['n_clustered'])
+    return {'queries': (b * st['sum_len_queries'] + 7) // 8, 'postings': 4 * st['posting_visits'],
+            'aligned_reps': (b * st['aligned_rep_len'] + 7) // 8, 'rep_residues': (b * st['sum_len_reps'] + 7) // 8,
+            'rep_words': 4 * st['rep_words'], 'outputs': 12 * st['n_clustered']}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='cfg-3s')
+    ap.add_argument('--workload', default=None, help='default: cfg-3s on one GPU, cfg-4 on several')
     ap.add_argument('--pancore-genes', type=int, default=150000)
     ap.add_argument('--pancore-iters', type=int, default=1000)
-    ap.add_argument('--cpu-sample-genomes', type=int, default=16)
+    ap.add_argument('--cpu-sample-genomes', type=int, default=100,
+                    help='CPU baseline: the oracle on the non-redundant set of the first K genomes (bounded sample)')
     ap.add_argument('--skip-cpu', action='store_true')
-    ap.add_argument('--shard', choices=['replicas', 'table'], default='replicas',
-                    help='N > 1: independent replicas (weak scaling, default) or ONE clustering job whose table '
-                         'pass is sharded over the ranks with a per-sweep all_reduce(MIN) over RCCL (strong scaling)')
+    ap.add_argument('--skip-e2e', action='store_true', help='skip the end-to-end build_cds_pangenome() measurement')
+    ap.add_argument('--e2e-genomes', type=int, default=0, help='genomes of the end-to-end run (0 = the whole workload)')
+    ap.add_argument('--shard', choices=['records', 'replicas'], default='records',
+                    help='N > 1: ONE clustering job sharded by record over the ranks (default, strong scaling) or N '
+                         'independent replicas (weak scaling)')
     ap.add_argument('--only', choices=['all', 'cluster', 'pancore'], default='all',
                     help='restrict the step (used for rocprofv3 counter passes); the JSON line needs all')
     args = ap.parse_args()
@@ -70,9 +84,11 @@ def main():
         raise SystemExit('bench.py needs a GPU (there is no CPU fallback)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    use_dist = world > 1 or (args.shard == 'table' and 'RANK' in os.environ)   # (torchrun with one rank rehearses RCCL)
+    use_dist = world > 1 or 'RANK' in os.environ   # (torchrun with one rank rehearses RCCL)
     if use_dist:
         dist.init_process_group('nccl', device_id=dev)
+    sharded = use_dist and args.shard == 'records'
+    workload = args.workload or ('cfg-4' if world > 1 else 'cfg-3s')
     ctx = _native.Context(local_rank)
     if rank == 0:
         log('device:', ctx.device_info())
@@ -80,18 +96,14 @@ def main():
 
     # ---- inputs (synthetic, deterministic), made resident in HBM ---------------------------
     t0 = time.perf_counter()
-    pset = synth.protein_set(args.workload)
-    res, off, n_raw = pset.nr_arrays(progress=100 if rank == 0 else None)
+    pset = synth.protein_set(workload)
+    res, off, n_raw = pset.nr_arrays(progress=200 if rank == 0 else None)
     n_nr = off.size - 1
     params = base_params = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
-    table_sharded = args.shard == 'table'
-    if table_sharded:   # every rank holds the same sequences; phase A of each sweep is split by representative
-        keys = torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device=dev)
-
-        def reduce_min(t):
-            if use_dist:
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        params, _keep = cluster.shard_params(params, rank, world, keys, reduce_min)
+    if sharded:   # every rank holds the same sequences; window member i belongs to rank i % world
+        send = torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device=dev)
+        recv = torch.empty((world, cluster.EXCHANGE_KEYS), dtype=torch.int64, device=dev)
+        params, _keep = cluster.shard_params(params, rank, world, send, recv, cluster.group_all_gather(dist.group.WORLD))
     d_res = torch.from_numpy(res.copy()).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     S = 400
@@ -99,55 +111,49 @@ def main():
     n_iter = args.pancore_iters
     np.random.seed(0)
     perms = pa.draw_permutations(S, n_iter)
+    it_lo, it_hi = pa.shard_bounds(n_iter, rank, world) if sharded else (0, n_iter)
+    my_iter = it_hi - it_lo
     stride = _native.lib().pgx_bitmap_stride_words(G)
     d_row, d_col = torch.from_numpy(row).to(dev), torch.from_numpy(col).to(dev)
     d_bits = torch.zeros((S, stride), dtype=torch.int64, device=dev)
-    d_perms = torch.from_numpy(perms).to(dev)
-    d_pan = torch.empty((n_iter, S), dtype=torch.int32, device=dev)
-    d_core = torch.empty((n_iter, S), dtype=torch.int32, device=dev)
-    ws_bytes = _native.lib().pgx_pan_core_workspace_bytes(G, S, n_iter)
+    d_perms = torch.from_numpy(perms[it_lo:it_hi].copy()).to(dev)
+    d_pan = torch.empty((max(my_iter, 1), S), dtype=torch.int32, device=dev)
+    d_core = torch.empty((max(my_iter, 1), S), dtype=torch.int32, device=dev)
+    ws_bytes = _native.lib().pgx_pan_core_workspace_bytes(G, S, max(my_iter, 1))
     d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     if rank == 0:
         log('inputs: %s -> %d raw records, %d non-redundant, %.1f M residues; pan/core %d x %d; %.1f s'
-            % (args.workload, n_raw, n_nr, res.size / 1e6, G, S, time.perf_counter() - t0))
+            % (workload, n_raw, n_nr, res.size / 1e6, G, S, time.perf_counter() - t0))
 
     last = {}
     wake = torch.empty(256, device=dev)
 
     def step(profile_cluster=False):
         t = time.perf_counter()
-        ctx.profile(profile_cluster)   # per-kernel events on ~10^4 small launches would perturb the timed run
+        ctx.profile(profile_cluster)   # per-kernel events on ~10^3 launches would perturb the timed run
         if args.only != 'pancore':
             last['cluster'] = ctx.cluster_greedy_dev(d_res.data_ptr(), d_off.data_ptr(), n_nr, res.size, params,
                                                      stream)
-        # The call returns with its results on the host: nothing of it is in flight any more. But its
-        # last ~10 ms are host-only (outputs, clean-up), the GPU drops into an idle state meanwhile, and
-        # the first kernel after it then needs 10-25 ms to start (measured: the pan/core kernels, 0.95 ms
-        # of GPU time, took 10-27 ms of wall time right after the call and 0.95 ms after one dummy kernel;
-        # a synchronize alone does not wake the device). One trivial kernel + synchronize bring the GPU
-        # back; their time is charged to the clustering (conservative), not to whatever runs next.
+        # The call returns with its results on the host: nothing of it is in flight any more. Its last
+        # milliseconds are host-only (outputs), the GPU drops into an idle state meanwhile, and the first
+        # kernel after it can need 10-25 ms to start. One trivial kernel + synchronize bring the GPU back;
+        # their time is charged to the clustering (conservative), not to whatever runs next.
         wake.zero_()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         ctx.profile(True)              # three launches: the events bracket the pan/core kernels live
-        ta = tb = time.perf_counter()
-        if args.only != 'cluster':
+        if args.only != 'cluster' and my_iter:
             ctx.presence_bitmap_dev(d_row.data_ptr(), d_col.data_ptr(), row.size, G, S, d_bits.data_ptr(), stream)
-            tb = time.perf_counter()
-            ctx.pan_core_dev(d_bits.data_ptr(), G, S, d_perms.data_ptr(), n_iter, d_pan.data_ptr(),
+            ctx.pan_core_dev(d_bits.data_ptr(), G, S, d_perms.data_ptr(), my_iter, d_pan.data_ptr(),
                              d_core.data_ptr(), d_ws.data_ptr(), ws_bytes, stream)
-        tc = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         ctx.profile(False)
-        if os.environ.get('PGX_TRACE'):
-            log('step: cluster %.2f ms | profile(True) %.3f bitmap-enqueue %.3f pancore-enqueue %.3f sync %.3f ms'
-                % ((t1 - t) * 1e3, (ta - t1) * 1e3, (tb - ta) * 1e3, (tc - tb) * 1e3, (t2 - tc) * 1e3))
         return t1 - t, t2 - t1
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -169,16 +175,15 @@ def main():
     step(profile_cluster=True)
     prof_all = ctx.profile_read()
     ctx.profile(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt, t_cluster, t_pancore], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, t_cluster, t_pancore = (float(x) for x in t.tolist())
-    if table_sharded and use_dist and args.only != 'pancore':   # work counters and identities are partial per rank
+    if sharded and args.only != 'pancore':   # work counters and identities are partial per rank
 
         def host_reduce(op):
             def f(a):
                 tt = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-                tt = tt.to(torch.int32) if tt.dtype == torch.uint8 else tt
                 dist.all_reduce(tt, op=op)
                 return tt.cpu().numpy().astype(a.dtype)
             return f
@@ -194,99 +199,182 @@ def main():
             dist.destroy_process_group()
         ctx.close()
         return
+
+    # ---- once-only measurements beside the timed steps (rank 0; the other ranks wait at the barrier) ------
+    extra = {}
     if rank == 0:
         import oracle
+        import scipy.sparse
+        from pangenomix_amd import pangenome, sparse_utils
         steps = args.steps
         cl, mem, iden, _, n_clusters, st = last['cluster']
         # parity spot checks of what was just timed (the oracle is the checker only)
-        pan, core = d_pan.cpu().numpy(), d_core.cpu().numpy()
-        sample = [0, n_iter - 1]
-        opan, ocore = oracle.pan_core(row, col, None, G, S, perms[sample])
-        assert np.array_equal(pan[sample], opan) and np.array_equal(core[sample], ocore), 'pan/core parity'
+        if my_iter:
+            pan, core = d_pan.cpu().numpy(), d_core.cpu().numpy()
+            sample = [0, my_iter - 1]
+            opan, ocore = oracle.pan_core(row, col, None, G, S, perms[it_lo:it_hi][sample])
+            assert np.array_equal(pan[sample], opan) and np.array_equal(core[sample], ocore), 'pan/core parity'
+        # clustering: size-independent properties of the result that was timed, and oracle parity on a prefix
+        lens = np.diff(off.astype(np.int64))
+        assert ((lens <= 10) == (cl < 0)).all(), 'discard rule'
+        assert (iden[mem > 0] >= np.float32(0.8)).all() and (iden[mem == 0] == 0).all(), 'identities'
+        assert int(cl.max()) + 1 == n_clusters == int((mem == 0).sum()), 'cluster numbering'
+        rep_of = np.full(n_clusters, -1, dtype=np.int64)
+        rep_of[cl[mem == 0]] = np.flatnonzero(mem == 0)
+        assert (lens[rep_of[cl[cl >= 0]]] >= lens[cl >= 0]).all(), 'a representative is the longest member'
+
+        if not sharded:   # (the multi-rank run keeps rank 0's extra work short: the others wait)
+            t = time.perf_counter()
+            hp = ctx.cluster_greedy(res, off, base_params)
+            extra['host_pointer_ms'] = (time.perf_counter() - t) * 1e3
+            assert np.array_equal(hp[0], cl) and np.array_equal(hp[1], mem), 'host-pointer entry point differs'
+            coo = scipy.sparse.coo_matrix((np.ones(row.size, dtype=np.int64), (row, col)), shape=(G, S))
+            lsdf = sparse_utils.LightSparseDataFrame(['g%d' % i for i in range(G)], ['s%d' % i for i in range(S)], coo)
+            best = None
+            with open(os.devnull, 'w') as null:
+                for _ in range(3):
+                    so, sys.stdout = sys.stdout, null
+                    try:
+                        t = time.perf_counter()
+                        np.random.seed(0)
+                        df = pa.estimate_pan_core_size(lsdf, n_iter, ctx=ctx)
+                        e = time.perf_counter() - t
+                    finally:
+                        sys.stdout = so
+                    best = e if best is None else min(best, e)
+            assert np.array_equal(df.values[[0, n_iter - 1], :S], d_pan.cpu().numpy()[[0, n_iter - 1]]), 'entry point differs'
+            extra['pan_core_entry_point'] = {'value': n_iter / best, 'unit': 'iters/s', 'ms': best * 1e3,
+                                             'what': 'estimate_pan_core_size(df_genes, %d): np.random.seed(0), value check, %d '
+                                                     'legacy-RNG shuffles, upload, bitmap + curves on the device, DataFrame'
+                                                     % (n_iter, n_iter)}
+        if not args.skip_e2e and not sharded:
+            sub = pset if not args.e2e_genomes else synth.ProteinSet(args.e2e_genomes, pset.cds, pset.F, pset.C, pset.seed)
+            tmp = tempfile.mkdtemp(prefix='pgx_e2e_')
+            try:
+                paths = sub.write_faa(os.path.join(tmp, 'genomes'))
+                os.mkdir(os.path.join(tmp, 'out'))
+                with open(os.devnull, 'w') as null:
+                    so, sys.stdout = sys.stdout, null
+                    try:
+                        t = time.perf_counter()
+                        dfa, dfg = pangenome.build_cds_pangenome(paths, os.path.join(tmp, 'out'), name='Bench')
+                        e2e = time.perf_counter() - t
+                    finally:
+                        sys.stdout = so
+                raw = sub.n_genomes * sub.cds
+                extra['end_to_end'] = {'value': raw / e2e, 'unit': 'raw records/s', 'seconds': e2e, 'genomes': sub.n_genomes,
+                                       'raw_records': raw, 'genes': int(dfg.shape[0]), 'alleles': int(dfa.shape[0]),
+                                       'what': 'build_cds_pangenome(): FASTA files in, dedupe, clustering, naming, tables, '
+                                               '.npz out (page cache warm)'}
+                if sub is pset:
+                    assert dfg.shape[0] == n_clusters, 'end-to-end gene count differs from the clustering'
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
 
         kern = {k: (v[0], v[1]) for k, v in prof_all.items()}   # one profiled step: (ms, launches)
-        sweep_ms = prof['pan_core_sweep_kernel'][0] / prof['pan_core_sweep_kernel'][1]
         words = (G + 63) // 64
-        pc_bytes = n_iter * (S * words * 8 + 2 * S * 4) + n_iter * S * 4
+        pc_bytes = my_iter * (S * words * 8 + 2 * S * 4) + my_iter * S * 4
+        sweep_ms = prof['pan_core_sweep_kernel'][0] / prof['pan_core_sweep_kernel'][1] if my_iter else float('nan')
         pc_gbs = pc_bytes / (sweep_ms * 1e-3) / 1e9
-        cl_bytes = cluster_algorithmic_bytes(st)
+        terms = cluster_terms(st)
+        cl_bytes = sum(terms.values())
         cl_gbs = cl_bytes / (t_cluster / steps) / 1e9
-        # HBM traffic per launch from rocprofv3 PMC passes of this same command, if a summary is committed
-        pmc = {}
-        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path)).get('kernels', {})
+        pmc, pmc_src = {}, None
+        if os.path.exists(os.path.join(ROOT, PMC_SUMMARY)):
+            pmc = json.load(open(os.path.join(ROOT, PMC_SUMMARY))).get('kernels', {})
+            pmc_src = 'static: %s (rocprofv3 --pmc passes of this command; not measured in this run)' % PMC_SUMMARY
 
-        def traffic(kernel):
-            e = pmc.get(kernel)
-            return None if not e else e.get('hbm_bytes_per_launch')
-        # the dominant kernel of the step by accumulated device time (profiled step)
-        dom = max(kern, key=lambda k_: kern[k_][0])
-        dom_ms, dom_n = kern[dom]
-        if dom == 'align_kernel':   # = align16_kernel (+ the rare wide pairs): residues of the aligned pairs + records
-            dom_name = 'align16_kernel'
-            dom_bytes = (5 * st['gpu']['aligned_bytes'] + 7) // 8 + 40 * st['gpu']['aligned']
-        elif dom == 'pan_core_sweep_kernel':
-            dom_name, dom_bytes = dom, pc_bytes
-        else:   # short-word filter passes: (u32 code + u16 mult) per streamed word, two u32 CSR offsets per
-                # look-up, one u32 posting entry per visit (the table pass dominates; others share the model)
-            dom_name = dom
-            dom_bytes = 14 * st['gpu']['table_stream_words'] + 4 * st['posting_visits']
-        dom_gbs = dom_bytes / (dom_ms * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'kernel': dom_name, 'achieved': dom_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': dom_gbs / HBM_PEAK_GBS, 'traffic': traffic(dom_name),
-                    'avg_kernel_ms': dom_ms / max(dom_n, 1), 'launches_per_step': dom_n,
-                    'algorithmic_bytes_per_launch': dom_bytes / max(dom_n, 1),
-                    'note': 'integer/latency-bound banded DP: the HBM fraction is small by nature (SURVEY 8d)'
-                    if dom_name == 'align16_kernel' else
-                    'gather-bound short-word filter (random 8-byte CSR look-ups): small HBM fraction by nature; '
-                    'since the sweep pipelining it runs on the side stream, off the critical path'
-                    if dom_name.startswith('count_kernel') else ''}
-        roofline_pc = {'bound': 'hbm', 'kernel': 'pan_core_sweep_kernel', 'achieved': pc_gbs, 'peak': HBM_PEAK_GBS,
-                       'unit': 'GB/s', 'frac': pc_gbs / HBM_PEAK_GBS, 'traffic': traffic('pan_core_sweep_kernel'),
+        def traffic(*names):
+            vals = [pmc[n_]['hbm_bytes_per_launch'] * pmc[n_].get('launches', 1) for n_ in names if n_ in pmc]
+            cnt = sum(pmc[n_].get('launches', 1) for n_ in names if n_ in pmc)
+            return sum(vals) / cnt if cnt else None
+        # kernel families of the clustering by accumulated device time (one profiled step)
+        fam = {'filter_kernel': ('filter_kernel<all>', 'filter_kernel<new>'), 'align_kernel': ('align_kernel',),
+               'diag_kernel': ('diag_kernel',)}
+        fam_ms = {f: sum(kern.get(k_, (0, 0))[0] for k_ in ks) for f, ks in fam.items()}
+        fam_n = {f: sum(kern.get(k_, (0, 0))[1] for k_ in ks) for f, ks in fam.items()}
+        dom = max(fam_ms, key=fam_ms.get)
+        # algorithmic bytes of that family: SURVEY 8d's own terms
+        alg = {'filter_kernel': terms['postings'],           # 4 * P: one 4-byte posting entry per visit
+               'align_kernel': terms['aligned_reps'],        # ceil(5 * A / 8): the aligned representatives' residues
+               'diag_kernel': terms['aligned_reps']}[dom]    # (the diagonal test reads the same representatives)
+        dom_ms, dom_n = fam_ms[dom], max(fam_n[dom], 1)
+        dom_gbs = alg / (dom_ms * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': dom, 'achieved': dom_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': dom_gbs / HBM_PEAK_GBS, 'traffic': traffic(*fam[dom]), 'traffic_source': pmc_src,
+                    'avg_kernel_ms': dom_ms / dom_n, 'launches_per_step': dom_n,
+                    'algorithmic_bytes_per_launch': alg / dom_n,
+                    'model': {'filter_kernel': '4 B x P posting visits of the sequential rule (SURVEY 8d)',
+                              'align_kernel': 'ceil(5 A / 8): residues of the aligned representatives (SURVEY 8d)',
+                              'diag_kernel': 'ceil(5 A / 8) (SURVEY 8d has no term of its own for the diagonal test)'}[dom],
+                    'implementation_traffic_model': {
+                        'filter line reads (64 B per query word and pass over the whole index)':
+                            64 * st['sum_len_queries'], 'note': 'what the layout moves, not algorithmic work'}}
+        roofline_pc = {'bound': 'l2', 'kernel': 'pan_core_sweep_kernel', 'achieved': pc_gbs, 'peak': L2_PEAK_GBS,
+                       'unit': 'GB/s', 'frac': pc_gbs / L2_PEAK_GBS, 'frac_of_hbm_peak': pc_gbs / HBM_PEAK_GBS,
+                       'traffic': traffic('pan_core_sweep_kernel'), 'traffic_source': pmc_src,
                        'avg_kernel_ms': sweep_ms, 'algorithmic_bytes_per_launch': pc_bytes,
-                       'note': 'matrix is L2-resident by design (XCD striping): the algorithmic rate exceeds HBM peak'}
+                       'note': 'the 7.5 MB matrix is L2-resident by design (XCD striping), so the roof is the aggregate L2 '
+                               '(34.5 TB/s); the same bytes against the 8 TB/s HBM peak are given beside it'}
+        extra.update(kern=kern, terms=terms, cl_bytes=cl_bytes, cl_gbs=cl_gbs, roofline=roofline, roofline_pc=roofline_pc)
 
         cpu = None
         if not args.skip_cpu:
-            sub = synth.ProteinSet(args.cpu_sample_genomes, pset.cds, pset.F, pset.C, pset.seed)
+            k_g = min(args.cpu_sample_genomes, pset.n_genomes)
+            sub = synth.ProteinSet(k_g, pset.cds, pset.F, pset.C, pset.seed)
             sres, soff, _ = sub.nr_arrays()
             t1 = time.perf_counter()
             ocl = oracle.cluster_greedy(sres, soff, base_params)
             cdt = time.perf_counter() - t1
+            # the sample doubles as a parity check of the library on the same sequences
+            gcl = ctx.cluster_greedy(sres, soff, base_params)
+            assert np.array_equal(gcl[0], ocl[0]) and np.array_equal(gcl[1], ocl[1]) and np.array_equal(gcl[2], ocl[2]), \
+                'clustering parity on the CPU sample'
             k = 20
             t1 = time.perf_counter()
             oracle.pan_core(row, col, None, G, S, perms[:k])
             pdt = time.perf_counter() - t1
             cpu = {'value': (soff.size - 1) / cdt, 'unit': 'proteins/s', 'cores': 1, 'kind': 'port',
-                   'sample': 'oracle/cluster_ref.c (sequential restatement of cd-hit) on the non-redundant set of '
-                             'the first %d of %d genomes: %d sequences, %d clusters, %.1f s; cd-hit itself is not '
-                             'installed. NB the per-sequence cost grows with the table, so the full-set CPU rate '
-                             'is lower.' % (args.cpu_sample_genomes, pset.n_genomes, soff.size - 1, ocl[4], cdt),
+                   'host_cores_available': os.cpu_count(),
+                   'sample': 'own restatement (oracle/cluster_ref.c, sequential; cd-hit itself is not installed) on the '
+                             'non-redundant set of the first %d of %d genomes: %d sequences, %d clusters, %.1f s on one core. '
+                             'The rule is sequential, so there is no all-cores figure; the per-sequence cost grows with '
+                             'the table: the full 400-genome set runs at about 16 k proteins/s (DESIGN.md).'
+                             % (k_g, pset.n_genomes, soff.size - 1, ocl[4], cdt),
                    'pan_core': {'value': k / pdt, 'unit': 'iters/s', 'cores': 1,
                                 'sample': '%d of %d iterations, oracle/pancore_ref.c (dense incidence loop of '
                                           'pangenome_analysis.py:81-90)' % (k, n_iter)}}
-        jobs = 1 if table_sharded else world   # independent jobs running side by side
+        extra['cpu'] = cpu
+    barrier()
+    if rank == 0:
+        steps = args.steps
+        cl, mem, iden, _, n_clusters, st = last['cluster']
+        jobs = 1 if (sharded or world == 1) else world   # independent jobs running side by side
         line = {
             'metric': 'proteins/sec clustered at 0.8 identity + pan/core iters/sec, 400-genome set',
             'value': jobs * n_nr * steps / t_cluster, 'unit': 'proteins/s', 'n_gpus': world, 'steps': steps,
             'warmup': args.warmup, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True,
-            'scaling': 'strong' if table_sharded else 'weak',
+            'scaling': 'weak' if jobs > 1 else 'strong',
             'vs_baseline': None, 'dtype': 'i32', 'data': 'synthetic',
             'config': {'workload': '%s: %d genomes x %d CDS synthetic (SURVEY 8d), %d raw records -> %d '
                                    'non-redundant proteins, %d clusters at -c 0.8 -n 5; pan/core %d iterations '
-                                   'on synthetic %d x %d matrix' % (args.workload, pset.n_genomes, pset.cds, n_raw,
+                                   'on synthetic %d x %d matrix' % (workload, pset.n_genomes, pset.cds, n_raw,
                                                                     n_nr, n_clusters, n_iter, G, S),
-                       'parallelism': ('table-sharded x%d: one job, phase A split by representative, all_reduce(MIN) of '
-                                       '4096 keys per sweep' % world) if table_sharded else 'replicas x%d' % world},
+                       'parallelism': ('record-sharded x%d: one job, window member i on rank i %% %d, all-gather of the '
+                                       'best keys per evaluation; pan/core iterations split' % (world, world)) if sharded
+                       else ('replicas x%d' % world if world > 1 else 'one GPU')},
             'pan_core': {'value': jobs * n_iter * steps / t_pancore, 'unit': 'iters/s',
-                         'ms': t_pancore / steps * 1e3, 'roofline': roofline_pc},
+                         'ms': t_pancore / steps * 1e3, 'roofline': extra['roofline_pc'],
+                         'entry_point': extra.get('pan_core_entry_point')},
             'cluster': {'ms': t_cluster / steps * 1e3, 'raw_records_per_s': jobs * n_raw * steps / t_cluster,
-                        'algorithmic_bytes': cl_bytes, 'achieved_GBs': cl_gbs, 'frac_hbm': cl_gbs / HBM_PEAK_GBS,
+                        'host_pointer_ms': extra.get('host_pointer_ms'),
+                        'algorithmic_bytes': extra['cl_bytes'], 'algorithmic_terms': extra['terms'],
+                        'achieved_GBs': extra['cl_gbs'], 'frac_hbm': extra['cl_gbs'] / HBM_PEAK_GBS,
                         'dp_cells_per_s': st['dp_cells'] / (t_cluster / steps), 'stats': st},
-            'roofline': roofline,
-            'cpu_baseline': cpu,
-            'kernels_ms_per_step': {k_: {'ms': round(v[0], 4), 'launches': v[1]} for k_, v in sorted(kern.items())},
+            'end_to_end': extra.get('end_to_end'),
+            'roofline': extra['roofline'],
+            'cpu_baseline': extra['cpu'],
+            'kernels_ms_per_step': {k_: {'ms': round(v[0], 4), 'launches': v[1]} for k_, v in sorted(extra['kern'].items())},
         }
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define PGX_VERSION 200 /* 0.2.0 */
-#define PGX_EXCHANGE_KEYS 32768u /* keys per process and exchange = the largest window */
+#define PGX_EXCHANGE_KEYS 65536u /* keys per process and exchange = the largest window */
 
 typedef enum pgx_status {
     PGX_OK = 0,

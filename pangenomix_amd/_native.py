@@ -25,7 +25,7 @@ class DeviceInfo(C.Structure):
 
 # int (*exchange)(void *user, void *stream): enqueue the all-gather of the window's best keys (pgx.h)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
-EXCHANGE_KEYS = 32768   # PGX_EXCHANGE_KEYS
+EXCHANGE_KEYS = 65536   # PGX_EXCHANGE_KEYS
 
 
 class ClusterParams(C.Structure):

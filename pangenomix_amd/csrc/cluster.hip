@@ -53,9 +53,10 @@ namespace {
 
 using namespace pgxc;
 
-constexpr uint32_t kWindowMax = 32768; // largest window (queries); first-open tags keep the member in 16 bits
-constexpr int kDiscoveryRounds = 2;    // device-only rounds before the block fallback
-constexpr uint32_t kBlockCap = 512;    // unassigned members resolved together inside a window
+constexpr uint32_t kWindowMax = 65536; // largest window (queries); first-open tags keep the member in 16 bits
+constexpr int kDiscoveryRounds = 1;    // device-only discovery rounds before the blocks
+constexpr uint32_t kBlockCap = 4096;   // most open members resolved together inside a window (512 for nucleotides)
+constexpr uint32_t kBlockCapMin = 64;  // what a block shrinks to when its candidate pairs overflow the buffer
 
 constexpr uint32_t kMaxLen = 32767;    // longest supported sequence
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
@@ -122,11 +123,6 @@ struct DevSeqs {
     int32_t nt;             // nucleotide rules
 };
 __device__ __forceinline__ uint32_t real_of(const DevSeqs &S, uint32_t k) { return k >= S.n_fwd ? k - S.n_fwd : k; }
-// batch slot -> sequence: slots [0, nbq) are the sweep's queries b0.., slots [nbq, 2 nbq) their
-// reverse complements (present only for nucleotides with both strands)
-__device__ __forceinline__ uint32_t slot_seq(const DevSeqs &S, uint32_t b0, uint32_t nbq, uint32_t s) {
-    return s < nbq ? b0 + s : S.n_fwd + b0 + (s - nbq);
-}
 
 // ----------------------------------------------------------------------------------------
 // prep: letter count per input sequence, then gather + encode into sorted order
@@ -421,6 +417,11 @@ struct FilterArgs {
     uint32_t pair_cap;
     unsigned long long *visits, *rc_visits;
     uint32_t *err;
+    // block mode: the queries are the block's members qlist[0 .. *d_nq) instead of the whole window; a member
+    // that gets a candidate is marked; visits are not counted (the entries are tentative)
+    const uint32_t *qlist, *d_nq;
+    uint8_t *mark;
+    uint32_t count_visits;
 };
 
 // multiplicity of `code` in the word list of sequence r (present by construction of the index);
@@ -550,11 +551,16 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     for (uint32_t i = lane; i < kFH; i += 64) { W.hrep[i] = kEmpty; W.hcnt[i] = 0u; W.hminc[i] = kSentinel; }
     wave_lds_sync();
 
-    for (uint32_t s = blockIdx.x * 4 + wave; s < A.ns; s += gridDim.x * 4) {
-        const uint32_t ql = s < A.nbq ? s : s - A.nbq;
-        if (A.shard_count > 1 && ql % A.shard_count != A.shard_index) continue;   // another process's member
+    const uint32_t n_list = A.qlist ? *A.d_nq : 0u;
+    const uint32_t n_slots = A.qlist ? (A.ns > A.nbq ? 2u * n_list : n_list) : A.ns;
+    for (uint32_t s = blockIdx.x * 4 + wave; s < n_slots; s += gridDim.x * 4) {
+        // window slot -> member, strand (block mode: slots enumerate the block list, then its reverse strands)
+        const uint32_t half = A.qlist ? n_list : A.nbq;
+        const bool rstrand = s >= half;
+        const uint32_t ql = A.qlist ? A.qlist[rstrand ? s - half : s] - A.b0 : (rstrand ? s - half : s);
+        if (A.shard_count > 1 && !A.qlist && ql % A.shard_count != A.shard_index) continue;   // another process's member
         const uint32_t q = A.b0 + ql;                     // the query (real sequence); candidates are r < q
-        const uint32_t k = slot_seq(S, A.b0, A.nbq, s);   // the strand walked
+        const uint32_t k = rstrand ? S.n_fwd + q : q;     // the strand walked
         const bool count_only = NEWONLY && A.done[ql];
         const int32_t t0 = A.req_aan[q];
         const uint32_t thr = t0 > 1 ? (uint32_t)t0 : 1u;
@@ -565,8 +571,8 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         filter_walk<NEWONLY, false>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full);
         wave_lds_sync();
         for (int d = 32; d > 0; d >>= 1) visits += __shfl_xor(visits, d);
-        if (visits && lane == 0) {
-            if (NT && s >= A.nbq) atomicAdd(&A.rc_visits[ql], (unsigned long long)visits);
+        if (visits && lane == 0 && A.count_visits) {
+            if (NT && rstrand) atomicAdd(&A.rc_visits[ql], (unsigned long long)visits);
             else atomicAdd(A.visits, (unsigned long long)visits);
         }
         if (__ballot(hot)) {
@@ -594,11 +600,12 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
                     const uint32_t c = W.hcnt[h], mc = W.hminc[h];
                     W.hrep[h] = kEmpty; W.hcnt[h] = 0u; W.hminc[h] = kSentinel;
                     if (over || c < thr) continue;
-                    const unsigned long long key = ((unsigned long long)(s >= A.nbq) << 63) | ((unsigned long long)mc << 32) | r;
+                    const unsigned long long key = ((unsigned long long)rstrand << 63) | ((unsigned long long)mc << 32) | r;
                     if (NEWONLY) {   // only candidates whose key can still beat the member's current best
                         const unsigned long long bo = A.best[ql];
                         if (bo != kNoBest && key > bo) continue;
                     }
+                    if (A.mark) A.mark[ql] = 1;
                     const uint32_t slot = atomicAdd(A.n_pairs, 1u);
                     if (slot < A.pair_cap) {
                         Pair p;
@@ -617,56 +624,25 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     }
 }
 
-// ----------------------------------------------------------------------------------------
-// in-block pairs: every (later, earlier) pair of a block of still-open members, exactly
-// ----------------------------------------------------------------------------------------
-// The fallback after the discovery rounds: the block (<= kBlockCap members, in order) is resolved
-// exactly -- all its in-block candidate pairs are found here, evaluated, and the host walks the
-// block in order. One wave per (member strand, earlier member): the earlier member's word list is
-// streamed (coalesced), each lane looks its word up in the later member's sorted list.
-__global__ __launch_bounds__(256) void block_pairs_kernel(DevSeqs S, const uint32_t *__restrict__ blk,
-                                                         const uint32_t *__restrict__ d_nblk, uint32_t b0,
-                                                         uint32_t both, const int32_t *__restrict__ req_aan,
-                                                         Pair *__restrict__ pairs, uint32_t *__restrict__ n_pairs,
-                                                         uint32_t pair_cap, uint8_t *__restrict__ has_cand) {
-    const uint32_t n = *d_nblk, lane = threadIdx.x & 63u;
-    const uint32_t strands = both ? 2u : 1u;
-    const uint64_t total = (uint64_t)n * (n - 1) / 2 * strands;
-    for (uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < total; w += (uint64_t)gridDim.x * 4) {
-        const uint32_t strand = (uint32_t)(w % strands);
-        const uint64_t pi = w / strands;
-        // pair index -> (i, j), j < i: i = the largest with i (i - 1) / 2 <= pi
-        uint32_t i = (uint32_t)((1.0 + sqrt(1.0 + 8.0 * (double)pi)) * 0.5);
-        while ((uint64_t)i * (i - 1) / 2 > pi) --i;
-        while ((uint64_t)(i + 1) * i / 2 <= pi) ++i;
-        const uint32_t j = (uint32_t)(pi - (uint64_t)i * (i - 1) / 2);
-        const uint32_t q = blk[i], r = blk[j];               // r earlier than q (the block list is in order)
-        const uint32_t kq = strand ? S.n_fwd + q : q;
-        const uint64_t oq = S.off[kq], orr = S.off[r];
-        const uint32_t nq = S.wcnt[kq], nr = S.wcnt[r];
-        uint32_t cnt = 0, minc = kSentinel;
-        for (uint32_t t = lane; t < nr; t += 64) {
-            const uint32_t code = S.wcode[orr + t];
-            uint32_t lo = 0, hi = nq;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (S.wcode[oq + mid] < code) lo = mid + 1; else hi = mid;
-            }
-            if (lo < nq && S.wcode[oq + lo] == code) {
-                const uint32_t a = S.wmult[oq + lo], b = S.wmult[orr + t];
-                cnt += a < b ? a : b;
-                minc = code < minc ? code : minc;
-            }
-        }
-        for (int d = 32; d > 0; d >>= 1) { cnt += __shfl_xor(cnt, d); const uint32_t m = __shfl_xor(minc, d); minc = m < minc ? m : minc; }
-        if (lane == 0 && cnt != 0u && (int32_t)cnt >= req_aan[q]) {
-            has_cand[q - b0] = 1;
-            const uint32_t slot = atomicAdd(n_pairs, 1u);
-            if (slot < pair_cap) {
-                Pair p;
-                p.q = kq; p.r = r; p.cnt = cnt; p.minc = minc;
-                p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
-                pairs[slot] = p;
+// Tentative entries: a block's members are appended to the index as if all of them were
+// representatives, so that the filter finds the block's internal candidate pairs the way it finds all
+// others; once the block is decided, the entries of the members that joined a representative are
+// struck out again (overwritten by an index no query precedes). One wave per member; the entries sit
+// in the part of their lists the round added.
+constexpr uint32_t kTombstone = 0x7FFFFFFFu;
+__global__ __launch_bounds__(256) void index_strike_kernel(DevSeqs S, const uint32_t *__restrict__ list, uint32_t n,
+                                                          IndexLine *__restrict__ lines, uint32_t *__restrict__ pool) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
+        const uint32_t k = list[w];
+        const uint64_t o = S.off[k];
+        const uint32_t nw = S.wcnt[k];
+        for (uint32_t i = lane; i < nw; i += 64) {
+            IndexLine &L = lines[S.wcode[o + i]];
+            const uint32_t hi = L.len;
+            for (uint32_t j = L.len_prev; j < hi; ++j) {
+                uint32_t *e = j < kInline ? &L.e[j] : &pool[L.ovf + 1u + (j - kInline)];
+                if ((*e & ~kMultiBit) == k) { *e = kTombstone; break; }
             }
         }
     }
@@ -737,7 +713,10 @@ __global__ __launch_bounds__(256) void first_open_kernel(DevSeqs S, const uint32
         const uint32_t k = ulist[w];
         const uint64_t o = S.off[k];
         const uint32_t nw = S.wcnt[k], tag = (epoch << 16) | (65535u - (k - b0));
-        for (uint32_t i = lane; i < nw; i += 64) atomicMax(&first[S.wcode[o + i]], tag);
+        for (uint32_t i = lane; i < nw; i += 64) {   // (members of one family share most words: mostly the read)
+            uint32_t *f = &first[S.wcode[o + i]];
+            if (*f < tag) atomicMax(f, tag);
+        }
     }
 }
 // A member can only have an earlier open candidate r if it shares at least its word threshold with
@@ -780,26 +759,19 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
 // [3] block size, [4] open members, [5] new representatives of the window (list length),
 // [6] begin of the current round's segment of that list, [7] touched codes of the round,
 // [8] error flag, [9] open members of the round
-enum { C_NW = 0, C_NK = 1, C_EVAL0 = 2, C_BLK = 3, C_OPEN = 4, C_NEW = 5, C_SEG0 = 6, C_TOUCH = 7, C_ERR = 8, C_ROUND_OPEN = 9, C_COUNT = 16 };
+enum { C_NW = 0, C_NK = 1, C_EVAL0 = 2, C_BLK = 3, C_OPEN = 4, C_NEW = 5, C_SEG0 = 6, C_TOUCH = 7, C_ERR = 8, C_ROUND_OPEN = 9, C_ZERO = 10, C_COUNT = 16 };
 
-// block members are final once the host has walked the block
-__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb) {
+// block members are final once the host has walked the block (final = 0: the block is given up, see the host)
+__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb, uint32_t final_) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nb && inblk[q]) { done[q] = 1; inblk[q] = 0; }
+    if (q < nb && inblk[q]) { done[q] = (uint8_t)final_; inblk[q] = 0; }
 }
+// start of a block's tentative append: no code touched yet, the block's pairs begin
+__global__ void block_begin_kernel(uint32_t *__restrict__ c) { c[C_TOUCH] = 0u; c[C_NK] = 0u; c[C_EVAL0] = c[C_NW]; }
 // start of a round: the pair range and list segment that the round's kernels work on begin here
 __global__ void round_begin_kernel(uint32_t *__restrict__ c) {
     c[C_EVAL0] = c[C_NW]; c[C_SEG0] = c[C_NEW]; c[C_TOUCH] = 0u; c[C_ROUND_OPEN] = 0u;
 }
-// a list of new representatives given by the host (block results): appended to the window's list
-__global__ __launch_bounds__(256) void push_list_kernel(const uint32_t *__restrict__ src, uint32_t n,
-                                                       uint32_t *__restrict__ list, uint32_t *__restrict__ c) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t base = c[C_SEG0];   // (= c[C_NEW] as round_begin left it; the new length is written by the next kernel)
-    if (i < n) list[base + i] = src[i];
-}
-__global__ void push_done_kernel(uint32_t n, uint32_t *__restrict__ c) { c[C_NEW] = c[C_SEG0] + n; }
-
 // Start of a window: counters, best keys, reverse-strand visit counters and member flags in one launch.
 __global__ __launch_bounds__(256) void window_init_kernel(uint32_t *__restrict__ counters,
                                                          unsigned long long *__restrict__ best,
@@ -807,6 +779,7 @@ __global__ __launch_bounds__(256) void window_init_kernel(uint32_t *__restrict__
                                                          uint8_t *__restrict__ flags, uint32_t window_cap) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // grid covers window_cap
     if (q < C_COUNT && q != C_ERR) counters[q] = 0u;
+    if (q >= window_cap) return;
     best[q] = kNoBest;
     if (rc_visits) rc_visits[q] = 0ull;
     if (q < 4 * window_cap / 8) reinterpret_cast<unsigned long long *>(flags)[q] = 0ull;
@@ -1678,7 +1651,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     const uint32_t window_cap = pgx_cluster_window_cap(P);           // queries per window
     PGX_REQUIRE(!P->exchange || window_cap <= PGX_EXCHANGE_KEYS, "window larger than PGX_EXCHANGE_KEYS");
     uint32_t pair_cap = 4u << 20;  // grows per window for nucleotides, whose word filter passes almost every pair
-    const uint32_t pair_cap_k = kBlockCap * kBlockCap + 16;  // every pair of one block, both strands
+    // blocks: nucleotide rules pass nearly every pair, so 512 members (all their pairs fit); proteins 4096
+    uint32_t block_cap = std::min(nt ? 512u : kBlockCap, window_cap);
+    const uint32_t pair_cap_k = nt ? 512u * 512u + 16u : (1u << 20);
     uint64_t max_window_words = 0;
     for (uint32_t b0 = 0; b0 < n; b0 += window_cap) {
         const uint32_t b1 = std::min(n, b0 + window_cap);
@@ -1722,7 +1697,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_first.alloc((size_t)n_codes * 4));
     PGX_HIP(d_best_own.alloc((size_t)window_cap * 8));
     PGX_HIP(d_rcvis.alloc((size_t)window_cap * 8));
-    PGX_HIP(d_blk_list.alloc(kBlockCap * 4));
+    PGX_HIP(d_blk_list.alloc((size_t)kBlockCap * 4));
     PGX_HIP(d_ulist.alloc((size_t)window_cap * 4));
     PGX_HIP(d_new_list.alloc((size_t)window_cap * 4));
     PGX_HIP(d_flags.alloc(4 * (size_t)window_cap));  // done, in-block, has-candidate, accepted
@@ -1820,7 +1795,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     constexpr uint32_t kPrefix = 65536;  // initial capacity (records) of the host copy of the window's pairs
     PGX_HIP(h_best.reserve(window_cap)); PGX_HIP(h_cnt.reserve(C_COUNT)); PGX_HIP(h_blk.reserve(kBlockCap));
     PGX_HIP(h_new.reserve(window_cap)); PGX_HIP(hK.reserve(pair_cap_k)); PGX_HIP(hW.reserve(kPrefix));
-    PGX_HIP(h_rcvis.reserve(window_cap)); PGX_HIP(h_push.reserve(window_cap));
+    PGX_HIP(h_rcvis.reserve(window_cap)); PGX_HIP(h_push.reserve(2 * (size_t)window_cap + 4 * kBlockCap));
     PGX_HIP(h_list.reserve(pair_cap_k)); PGX_HIP(h_gather.reserve(pair_cap_k));
     uint32_t *dc = d_counters.as<uint32_t>();
     unsigned long long *d_rcvis_p = d_rcvis.as<unsigned long long>();
@@ -1901,8 +1876,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         FA.req_aan = d_aan.as<int32_t>(); FA.best = d_best; FA.done = d_done;
         FA.pairs = pairsW; FA.n_pairs = dc + C_NW; FA.pair_cap = pair_cap;
         FA.visits = d_visits.as<unsigned long long>(); FA.rc_visits = d_rcvis_p; FA.err = dc + C_ERR;
+        FA.qlist = nullptr; FA.d_nq = nullptr; FA.mark = nullptr; FA.count_visits = 1u;
 
-        window_init_kernel<<<window_cap / 256, 256, 0, st>>>(dc, d_best, both ? d_rcvis_p : nullptr, d_done, window_cap);
+        window_init_kernel<<<(window_cap + 255) / 256, 256, 0, st>>>(dc, d_best, both ? d_rcvis_p : nullptr, d_done, window_cap);
         LAUNCH_CHECK();
         // diag + align of a selection of pair records, enqueued on the stream
         auto evaluate = [&](Pair *pairs, const PairSel &sel, unsigned long long *best_arr, uint32_t grid_hint) -> int {
@@ -1953,34 +1929,36 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 kern<<<std::min(filter_grid, (ns + 3) / 4), 256, 0, st>>>(DS, FA);
             }
             LAUNCH_CHECK();
-            filter_walk_words += window_words * (both ? 2 : 1);
+            filter_walk_words += window_words * (both ? 2 : 1) / shard_count;
             int rc = evaluate_round();
             if (rc) return rc;
         }
-        // append list[C_SEG0, C_NEW) to the index and compare every later window member with the new entries
-        auto append_and_filter = [&]() -> int {
+        // append list[*lo, *hi) to the index as round `epoch_idx` (the bit map of touched codes is the round's)
+        auto index_append = [&](const uint32_t *list, const uint32_t *d_lo, const uint32_t *d_hi) -> int {
             ++epoch_idx;
             PGX_HIP(hipMemsetAsync(d_newbits.p, 0, ((size_t)n_codes / 32 + 2) * 4, st));
-            {
-                ProfScope prof(ctx, "index_append", st);
-                index_count_kernel<<<512, 256, 0, st>>>(DS, d_new_list.as<uint32_t>(), dc + C_SEG0, dc + C_NEW,
-                                                        d_lines.as<IndexLine>(), d_touched.as<uint32_t>(), dc + C_TOUCH,
-                                                        (uint32_t)max_window_words, dc + C_ERR);
-                index_grow_kernel<<<512, 256, 0, st>>>(d_lines.as<IndexLine>(), d_poolp, d_idx.as<uint32_t>(),
-                                                       (uint32_t)pool_cap, d_touched.as<uint32_t>(), dc + C_TOUCH,
-                                                       (uint32_t)max_window_words, epoch_idx, d_newbits.as<uint32_t>(),
-                                                       dc + C_ERR);
-                index_write_kernel<<<512, 256, 0, st>>>(DS, d_new_list.as<uint32_t>(), dc + C_SEG0, dc + C_NEW,
-                                                        d_lines.as<IndexLine>(), d_poolp);
-            }
+            ProfScope prof(ctx, "index_append", st);
+            index_count_kernel<<<512, 256, 0, st>>>(DS, list, d_lo, d_hi, d_lines.as<IndexLine>(), d_touched.as<uint32_t>(),
+                                                    dc + C_TOUCH, (uint32_t)max_window_words, dc + C_ERR);
+            index_grow_kernel<<<512, 256, 0, st>>>(d_lines.as<IndexLine>(), d_poolp, d_idx.as<uint32_t>(),
+                                                   (uint32_t)pool_cap, d_touched.as<uint32_t>(), dc + C_TOUCH,
+                                                   (uint32_t)max_window_words, epoch_idx, d_newbits.as<uint32_t>(),
+                                                   dc + C_ERR);
+            index_write_kernel<<<512, 256, 0, st>>>(DS, list, d_lo, d_hi, d_lines.as<IndexLine>(), d_poolp);
             LAUNCH_CHECK();
-            FA.epoch = epoch_idx;
+            return PGX_OK;
+        };
+        // every window member against the entries round `epoch_idx` added (the representatives list[*lo, *hi))
+        auto filter_new_and_evaluate = [&](const uint32_t *d_lo, const uint32_t *d_hi) -> int {
+            FilterArgs F = FA;
+            F.epoch = epoch_idx; F.d_round_lo = d_lo; F.d_round_hi = d_hi;
             {
                 ProfScope prof(ctx, "filter_kernel<new>", st);
                 auto kern = nt ? filter_kernel<true, true> : filter_kernel<false, true>;
-                kern<<<std::min(filter_grid, (ns + 3) / 4), 256, 0, st>>>(DS, FA);
+                kern<<<std::min(filter_grid, (ns + 3) / 4), 256, 0, st>>>(DS, F);
             }
             LAUNCH_CHECK();
+            filter_walk_words += window_words * (both ? 2 : 1) / shard_count;
             return evaluate_round();
         };
         // Discovery rounds: still-open members that cannot have an earlier open candidate are certain new
@@ -2003,26 +1981,37 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                                                                               dc + C_NEW);
             }
             LAUNCH_CHECK();
-            filter_walk_words += window_words * (both ? 2 : 1);
-            int rc = append_and_filter();
+            int rc = index_append(d_new_list.as<uint32_t>(), dc + C_SEG0, dc + C_NEW);
+            if (rc) return rc;
+            rc = filter_new_and_evaluate(dc + C_SEG0, dc + C_NEW);
             if (rc) return rc;
         }
-        // Blocks: members still without a representative, <= kBlockCap at a time, in order. A block is
-        // resolved exactly (all its in-block pairs are found and evaluated, then the host walks it in
-        // order); every later member is then compared with the block's NEW representatives only, so
-        // pair work stays close to what the one-by-one pass would do.
+        // Blocks: members still without a representative, <= block_cap at a time, in order. A block is
+        // resolved exactly: its members are appended to the index TENTATIVELY, as if all were
+        // representatives, so the filter finds the block's internal candidate pairs like any others;
+        // they are evaluated, the host walks the block in order, the entries of the members that joined a
+        // representative are struck out again, and every other window member is compared with what is
+        // left: the block's new representatives. Pair work stays close to what the one-by-one pass does.
         bool first_block = true;
-        uint32_t n_listed = 0;   // entries of the window's new-representative list the host has seen
+        uint32_t n_listed = 0;     // discovery representatives the host has seen
+        uint32_t n_struck = 0;     // members struck out of the index so far (offsets into the pinned list)
         for (;;) {
-            select_block_kernel<<<1, kSelThreads, 0, st>>>(d_best, d_done, d_inblk, b0, nb, kBlockCap,
+            select_block_kernel<<<1, kSelThreads, 0, st>>>(d_best, d_done, d_inblk, b0, nb, block_cap,
                                                            d_blk_list.as<uint32_t>(), dc + C_BLK, dc + C_NK,
                                                            d_hascand, window_cap);  // + has_cand, accepted = 0
+            block_begin_kernel<<<1, 1, 0, st>>>(dc);
             LAUNCH_CHECK();
             {
-                ProfScope prof(ctx, "block_pairs_kernel", st);
-                block_pairs_kernel<<<2048, 256, 0, st>>>(DS, d_blk_list.as<uint32_t>(), dc + C_BLK, b0, both ? 1u : 0u,
-                                                         d_aan.as<int32_t>(), d_pairsK.as<Pair>(), dc + C_NK, pair_cap_k,
-                                                         d_hascand);
+                int rc = index_append(d_blk_list.as<uint32_t>(), dc + C_ZERO, dc + C_BLK);
+                if (rc) return rc;
+                FilterArgs F = FA;   // the block's members against the block's (tentative) entries
+                F.epoch = epoch_idx; F.d_round_lo = dc + C_ZERO; F.d_round_hi = dc + C_BLK;
+                F.qlist = d_blk_list.as<uint32_t>(); F.d_nq = dc + C_BLK; F.mark = d_hascand; F.count_visits = 0u;
+                F.pairs = d_pairsK.as<Pair>(); F.n_pairs = dc + C_NK; F.pair_cap = pair_cap_k;
+                F.shard_count = 1; F.shard_index = 0;   // (replicated on every process)
+                ProfScope prof(ctx, "filter_kernel<block>", st);
+                auto kern = nt ? filter_kernel<true, true> : filter_kernel<false, true>;
+                kern<<<std::min(filter_grid, (block_cap * (both ? 2u : 1u) + 3) / 4), 256, 0, st>>>(DS, F);
             }
             LAUNCH_CHECK();
             // A block member without an earlier in-block candidate (has_cand clear) is certainly a
@@ -2044,7 +2033,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             {
                 PubArgs pa{};
                 pa.seg[0] = {dc, h_cnt.p, nullptr, C_COUNT, 1, C_COUNT};
-                pa.seg[1] = {d_blk_list.as<uint32_t>(), h_blk.p, dc + C_BLK, 0, 1, kBlockCap};
+                pa.seg[1] = {d_blk_list.as<uint32_t>(), h_blk.p, dc + C_BLK, 0, 1, block_cap};
                 pa.seg[2] = {d_pairsK.as<uint32_t>(), reinterpret_cast<uint32_t *>(hK.p), dc + C_NK, 0, kPairWords, pair_cap_k};
                 pa.n = 3;
                 if (first_block) pa.seg[pa.n++] = {d_new_list.as<uint32_t>(), h_new.p, dc + C_NEW, 0, 1, window_cap};
@@ -2069,10 +2058,25 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 first_block = false;
             }
             const uint32_t n_blk = h_cnt.p[C_BLK], n_open = h_cnt.p[C_OPEN], nK = h_cnt.p[C_NK];
-            if (h_cnt.p[C_NW] > pair_cap || nK > pair_cap_k) {
-                pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u / %u) in the window at %u",
-                              h_cnt.p[C_NW], nK, b0);
+            if (h_cnt.p[C_NW] > pair_cap) {
+                pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u) in the window at %u", h_cnt.p[C_NW], b0);
                 return PGX_ERR_CAPACITY;
+            }
+            if (nK > pair_cap_k) {
+                // more in-block candidate pairs than the buffer holds: give the block up (all its tentative
+                // entries are struck out again) and come back with a quarter of the members
+                if (block_cap <= kBlockCapMin) {
+                    pgx_set_error("pgx_cluster_greedy: block pair buffer overflow (%u) in the window at %u", nK, b0);
+                    return PGX_ERR_CAPACITY;
+                }
+                uint32_t *list = h_push.p + n_struck;
+                std::copy(h_blk.p, h_blk.p + n_blk, list);
+                n_struck += n_blk;
+                index_strike_kernel<<<std::min(1024u, (n_blk + 3) / 4), 256, 0, st>>>(DS, list, n_blk, d_lines.as<IndexLine>(), d_poolp);
+                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, 0u);
+                LAUNCH_CHECK();
+                block_cap = std::max(kBlockCapMin, block_cap / 4);
+                continue;
             }
             if (n_blk == 0) break;
             // resolve the block in order: first accepted in-block representative by (minc, index)
@@ -2170,21 +2174,20 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             }
             if (count_replicated) account(hK.p, nK);
             t_resolve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_r0).count();
-            // later members against the block's new representatives (on the device)
-            if (!new_reps.empty()) {
-                const uint32_t nr = (uint32_t)new_reps.size();
-                // the list is read from page-locked host memory; every block has its own range, so nothing
-                // in flight is overwritten
-                uint32_t *list = h_push.p + n_listed;
-                std::copy(new_reps.begin(), new_reps.end(), list);
-                n_listed += nr;
-                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb);
-                round_begin_kernel<<<1, 1, 0, st>>>(dc);
-                push_list_kernel<<<(nr + 255) / 256, 256, 0, st>>>(list, nr, d_new_list.as<uint32_t>(), dc);
-                push_done_kernel<<<1, 1, 0, st>>>(nr, dc);
+            // the members that joined a representative leave the index again; every window member is then
+            // compared with the block's representatives (the block's own members only count their visits)
+            {
+                uint32_t *list = h_push.p + n_struck;   // read from page-locked host memory; every block has its own range
+                uint32_t n_out = 0;
+                for (uint32_t t = 0; t < n_blk; ++t)
+                    if (status[h_blk.p[t] - b0] != ST_REP) list[n_out++] = h_blk.p[t];
+                n_struck += n_out;
+                if (n_out)
+                    index_strike_kernel<<<std::min(1024u, (n_out + 3) / 4), 256, 0, st>>>(DS, list, n_out, d_lines.as<IndexLine>(), d_poolp);
+                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, 1u);
+                block_begin_kernel<<<1, 1, 0, st>>>(dc);
                 LAUNCH_CHECK();
-                filter_walk_words += window_words * (both ? 2 : 1);
-                int rc = append_and_filter();
+                int rc = filter_new_and_evaluate(dc + C_ZERO, dc + C_BLK);
                 if (rc) return rc;
             }
             if (n_open == n_blk) break;  // that was the last block

@@ -55,7 +55,7 @@ class Model(object):
         return None if cnt < self.thr[q] else np.uint64((minc << 32) | r)
 
 
-def run(seqs, params, oracle, pack, rank, world, all_gather, fold, owner_of, window=16, keys_cap=32768):
+def run(seqs, params, oracle, pack, rank, world, all_gather, fold, owner_of, window=16, keys_cap=65536):
     """Cluster `seqs` as process `rank` of `world`. all_gather(recv, send, stream) / fold(rows) /
     owner_of(member, world) are the product's helpers. Returns cluster numbers in input order
     (-1 = discarded) and the number of pairs THIS rank evaluated."""
