@@ -54,7 +54,7 @@ namespace {
 using namespace pgxc;
 
 constexpr uint32_t kWindowMax = 65536; // largest window (queries); first-open tags keep the member in 16 bits
-constexpr int kDiscoveryRounds = 1;    // device-only discovery rounds before the blocks
+constexpr int kDiscoveryRounds = 2;    // device-only discovery rounds before the blocks
 constexpr uint32_t kBlockCap = 4096;   // most open members resolved together inside a window (512 for nucleotides)
 constexpr uint32_t kBlockCapMin = 64;  // what a block shrinks to when its candidate pairs overflow the buffer
 
@@ -701,51 +701,93 @@ __global__ __launch_bounds__(256) void list_open_kernel(const unsigned long long
     if (q >= nb) return;
     if (!done[q] && best[q] == kNoBest) ulist[atomicAdd(n_open, 1u)] = b0 + q;
 }
-// Discovery of certain representatives in time linear in the open members' words. first[code]
-// holds, tagged with the round's epoch, the earliest open member whose word list has `code`
-// (epoch << 16 | 65535 - member: a plain atomicMax keeps the earliest member of the newest epoch;
-// no per-round reset).
+// Discovery of certain representatives in time linear in the open members' words.
+//
+// A member u can only have an earlier open candidate r if it shares at least its word threshold with
+// r; the words it shares with r are among its words that ANY open member of r's part of the window
+// has. The window is cut into <= 32 consecutive CHUNKS of bounded word volume (so that the words of
+// one chunk cover only a fraction of the code space well below the threshold fraction: what unrelated
+// members contribute by chance stays below any threshold, however large the window is), and two
+// tables are filled from the open members' word lists:
+//   chunk_bits[code]      bit t set: some open member of chunk t has the word
+//   first[c][code]        per chunk c: the earliest open member of the chunk that has the word, tagged
+//                         with the round's epoch (epoch << 16 | 65535 - member: a plain atomicMax keeps the
+//                         earliest member of the newest epoch; no per-round reset)
+// For member u of chunk c: the multiplicities of its words whose first[c] tag is earlier than u, and,
+// per earlier chunk t, those of its words with bit t set. When every one of these sums stays below u's
+// threshold (on both strands), no earlier open member can be its candidate: u is a new
+// representative for certain -- appended to the window's list of new representatives and made final.
+// Typically that is the first member of every family that appears in the window.
+constexpr uint32_t kMaxChunks = 32;
+struct Chunks { uint32_t n; uint32_t begin[kMaxChunks + 1]; };   // member ql belongs to chunk c: begin[c] <= ql < begin[c+1]
+__device__ __forceinline__ uint32_t chunk_of(const Chunks &C, uint32_t ql) {
+    uint32_t c = 0;
+    for (uint32_t t = 1; t < C.n; ++t) c += ql >= C.begin[t];
+    return c;
+}
 __global__ __launch_bounds__(256) void first_open_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
                                                         const uint32_t *__restrict__ n_open, uint32_t b0,
-                                                        uint32_t epoch, uint32_t *__restrict__ first) {
+                                                        uint32_t epoch, uint32_t *__restrict__ first, uint32_t n_codes,
+                                                        uint32_t *__restrict__ chunk_bits, Chunks C) {
     const uint32_t lane = threadIdx.x & 63u, n = *n_open;
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
-        const uint32_t k = ulist[w];
+        const uint32_t k = ulist[w], ql = k - b0, c = chunk_of(C, ql);
         const uint64_t o = S.off[k];
-        const uint32_t nw = S.wcnt[k], tag = (epoch << 16) | (65535u - (k - b0));
-        for (uint32_t i = lane; i < nw; i += 64) {   // (members of one family share most words: mostly the read)
-            uint32_t *f = &first[S.wcode[o + i]];
-            if (*f < tag) atomicMax(f, tag);
+        const uint32_t nw = S.wcnt[k], tag = (epoch << 16) | (65535u - ql), bit = 1u << c;
+        uint32_t *tab = first + (size_t)c * n_codes;
+        for (uint32_t i = lane; i < nw; i += 64) {   // (members of one family share most words: mostly the reads)
+            const uint32_t code = S.wcode[o + i];
+            if (tab[code] < tag) atomicMax(&tab[code], tag);
+            if (!(chunk_bits[code] & bit)) atomicOr(&chunk_bits[code], bit);
         }
     }
 }
-// A member can only have an earlier open candidate r if it shares at least its word threshold with
-// r, and the words it shares with r are among its words that ANY earlier open member has. When even
-// that count stays below the threshold (on both strands) the member is a new representative for
-// certain: appended to the window's list of new representatives and made final. Typically that is
-// the first member of every family that appears in the window. One wave per member.
+// One wave per open member.
 __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
                                                      const uint32_t *__restrict__ n_open, uint32_t b0,
                                                      uint32_t both, uint32_t epoch,
-                                                     const uint32_t *__restrict__ first,
+                                                     const uint32_t *__restrict__ first, uint32_t n_codes,
+                                                     const uint32_t *__restrict__ chunk_bits, Chunks C,
                                                      const int32_t *__restrict__ req_aan,
                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ list,
                                                      uint32_t *__restrict__ n_list) {
+    __shared__ uint32_t s_cnt[4][kMaxChunks];
     const uint32_t lane = threadIdx.x & 63u, n = *n_open;
+    uint32_t *cnt = s_cnt[threadIdx.x >> 6];
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
-        const uint32_t k = ulist[w], ql = k - b0;
+        const uint32_t k = ulist[w], ql = k - b0, c = chunk_of(C, ql);
+        const uint32_t *tab = first + (size_t)c * n_codes;
+        const uint32_t earlier = (1u << c) - 1u;
+        const int32_t t0 = req_aan[k];
         bool cand = false;
         for (uint32_t strand = 0; strand < (both ? 2u : 1u) && !cand; ++strand) {
             const uint32_t ks = strand ? S.n_fwd + k : k;
             const uint64_t o = S.off[ks];
             const uint32_t nw = S.wcnt[ks];
+            if (lane < kMaxChunks) cnt[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
             uint32_t sum = 0;
             for (uint32_t i = lane; i < nw; i += 64) {
-                const uint32_t f = first[S.wcode[o + i]];
-                if ((f >> 16) == epoch && 65535u - (f & 65535u) < ql) sum += S.wmult[o + i];
+                const uint32_t code = S.wcode[o + i], m = S.wmult[o + i];
+                const uint32_t f = tab[code];
+                if ((f >> 16) == epoch && 65535u - (f & 65535u) < ql) sum += m;
+                uint32_t bits = chunk_bits[code] & earlier;
+                while (bits) {
+                    const uint32_t t = (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    atomicAdd(&cnt[t], m);
+                }
             }
             for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
-            cand = sum != 0u && (int32_t)sum >= req_aan[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint32_t mx = lane < c ? cnt[lane] : 0u;
+            mx = mx > sum ? mx : sum;
+            for (int d = 32; d > 0; d >>= 1) { const uint32_t v = __shfl_xor(mx, d); mx = v > mx ? v : mx; }
+            cand = mx != 0u && (int32_t)mx >= t0;
+            __builtin_amdgcn_wave_barrier();
         }
         if (!cand && lane == 0) {
             done[ql] = 1;
@@ -1654,10 +1696,37 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     // blocks: nucleotide rules pass nearly every pair, so 512 members (all their pairs fit); proteins 4096
     uint32_t block_cap = std::min(nt ? 512u : kBlockCap, window_cap);
     const uint32_t pair_cap_k = nt ? 512u * 512u + 16u : (1u << 20);
+    // A window = consecutive members: at most window_cap of them, in at most kMaxChunks chunks of bounded word
+    // volume (see certain_kernel: the words of one chunk must cover a fraction of the code space well below
+    // the word threshold fraction, or unrelated members alone would defeat the discovery test).
+    const double thr_frac = P->identity > 0.95 ? std::max(0.0, 1.0 - (1.0 - P->identity) * P->word_len) : P->aan_cutoff;
+    // (a code space too small for that -- nucleotide 5-mers, tiny thresholds -- gets one chunk per window: the
+    // discovery test then certifies little and the exact block resolution does the work)
+    const uint64_t chunk_words = (uint64_t)(0.4 * thr_frac * (double)n_codes);
+    const bool chunking = chunk_words >= 16384;
+    auto form_window = [&](uint32_t b0, Chunks &C) -> uint32_t {
+        C.n = 1; C.begin[0] = 0;
+        uint64_t in_chunk = 0;
+        uint32_t q = 0;
+        for (; b0 + q < n && q < window_cap; ++q) {
+            const uint64_t w = h_len[b0 + q];
+            if (chunking && in_chunk && in_chunk + w > chunk_words) {
+                if (C.n == kMaxChunks) break;
+                C.begin[C.n++] = q;
+                in_chunk = 0;
+            }
+            in_chunk += w;
+        }
+        C.begin[C.n] = q;
+        return q;
+    };
     uint64_t max_window_words = 0;
-    for (uint32_t b0 = 0; b0 < n; b0 += window_cap) {
-        const uint32_t b1 = std::min(n, b0 + window_cap);
-        max_window_words = std::max<uint64_t>(max_window_words, h_off[b1] - h_off[b0]);
+    {
+        Chunks C;
+        for (uint32_t b0 = 0, nbw; b0 < n; b0 += nbw) {
+            nbw = form_window(b0, C);
+            max_window_words = std::max<uint64_t>(max_window_words, h_off[b0 + nbw] - h_off[b0]);
+        }
     }
     PGX_REQUIRE(max_window_words < 0xFFFFFFF0ull, "window too large");
     const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsCap;
@@ -1665,11 +1734,11 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     const uint32_t gs_stride = 3u * ((max_len + 64u) & ~63u);  // per workgroup: 2 L diagonals + L query positions
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_lines, d_pool[2], d_idx,
-        d_newbits, d_touched, d_first, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
+        d_newbits, d_touched, d_first, d_chunkbits, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
         d_ulist, d_new_list, d_flags, d_gscratch, d_order, d_list, d_gather, d_pk, d_pkoff;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_lines,
-                         &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_best_own, &d_rcvis,
+                         &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_chunkbits, &d_best_own, &d_rcvis,
                          &d_counters, &d_visits, &d_pairsW, &d_pairsK, &d_blk_list, &d_ulist, &d_new_list, &d_flags,
                          &d_gscratch, &d_order, &d_list, &d_gather, &d_pk, &d_pkoff};
         int sl = 1;
@@ -1694,7 +1763,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_idx.alloc(16));
     PGX_HIP(d_newbits.alloc(((size_t)n_codes / 32 + 2) * 4));
     PGX_HIP(d_touched.alloc((max_window_words + 16) * 4));
-    PGX_HIP(d_first.alloc((size_t)n_codes * 4));
+    PGX_HIP(d_first.alloc((size_t)kMaxChunks * n_codes * 4));   // per-chunk first-open tags
+    PGX_HIP(d_chunkbits.alloc((size_t)n_codes * 4));
     PGX_HIP(d_best_own.alloc((size_t)window_cap * 8));
     PGX_HIP(d_rcvis.alloc((size_t)window_cap * 8));
     PGX_HIP(d_blk_list.alloc((size_t)kBlockCap * 4));
@@ -1834,15 +1904,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     const uint32_t filter_grid = 4096u;
     uint32_t epoch_idx = 0;      // append rounds of the index (line.epoch); 0 = never
     uint32_t epoch_tag = 0;      // discovery rounds (first-open tags, 16 bits)
-    PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)n_codes * 4, st));
+    PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)kMaxChunks * n_codes * 4, st));
     phase("window set-up");
     const auto t_loop0 = std::chrono::steady_clock::now();
     double t_resolve = 0.0, t_close = 0.0;
     uint64_t n_blocks = 0;
     g_wait_s = 0.0;
     std::function<int()> deferred;  // bookkeeping of the window before, see the close of a window
-    for (uint32_t b0 = 0; b0 < n; b0 += window_cap) {
-        const uint32_t nb = std::min(window_cap, n - b0);  // queries of this window
+    Chunks chunks;
+    for (uint32_t b0 = 0, nb; b0 < n; b0 += nb) {
+        nb = form_window(b0, chunks);                      // queries of this window
         const uint32_t ns = both ? 2 * nb : nb;            // window slots: + one per reverse complement
         const uint32_t n_reps = (uint32_t)rep_seq.size();
         const uint64_t window_words = h_off[b0 + nb] - h_off[b0];
@@ -1967,16 +2038,19 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // the members the first round's representatives rejected (the outliers of their families). All on
         // the device: the host learns the outcome with the first block's results.
         for (int round = 0; round < kDiscoveryRounds; ++round) {
-            if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)n_codes * 4, st)); epoch_tag = 1; }
+            if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)kMaxChunks * n_codes * 4, st)); epoch_tag = 1; }
+            PGX_HIP(hipMemsetAsync(d_chunkbits.p, 0, (size_t)n_codes * 4, st));
             round_begin_kernel<<<1, 1, 0, st>>>(dc);
             list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN);
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "discover_kernels", st);
                 first_open_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
-                                                                                 epoch_tag, d_first.as<uint32_t>());
+                                                                                 epoch_tag, d_first.as<uint32_t>(), n_codes,
+                                                                                 d_chunkbits.as<uint32_t>(), chunks);
                 certain_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
-                                                                              both ? 1u : 0u, epoch_tag, d_first.as<uint32_t>(),
+                                                                              both ? 1u : 0u, epoch_tag, d_first.as<uint32_t>(), n_codes,
+                                                                              d_chunkbits.as<uint32_t>(), chunks,
                                                                               d_aan.as<int32_t>(), d_done, d_new_list.as<uint32_t>(),
                                                                               dc + C_NEW);
             }
