@@ -17,7 +17,7 @@
 // one wave per query walks the lines of the query's words, so a query touches exactly the posting
 // entries the sequential rule visits.
 //
-// One WINDOW handles up to 16384 consecutive queries (nucleotides, both strands: each query has a
+// One WINDOW handles up to 32768 consecutive queries (nucleotides, both strands: each query has a
 // second slot for its reverse complement):
 //   phase A   filter over the whole index (representatives of earlier windows) -> candidate pairs
 //             -> diag (k-mer diagonal histogram, best band) -> align (banded DP on the anti-diagonal
@@ -1543,7 +1543,7 @@ extern "C" uint32_t pgx_cluster_window_cap(const pgx_cluster_params *P) {
     if (!P) return 0;
     const bool both = P->alphabet == 1 && P->both_strands != 0;
     // nucleotide rules at the reference's -n 5 -c 0.8 pass any pair that shares one word: small windows
-    uint32_t w = P->alphabet == 1 ? (both ? 2048u : 4096u) : 16384u;
+    uint32_t w = P->alphabet == 1 ? (both ? 2048u : 4096u) : 32768u;
     if (P->batch_size > 0) w = (uint32_t)P->batch_size;
     if (const char *e = std::getenv("PGX_WINDOW")) { const long v = std::atol(e); if (v > 0) w = (uint32_t)v; }
     w = std::max(w, 64u);
