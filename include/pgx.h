@@ -208,6 +208,58 @@ int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, const uint64
                            int32_t *out_member, float *out_identity, uint8_t *out_strand,
                            uint32_t *out_n_clusters, pgx_cluster_stats *stats, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Host side of the pipeline around the clustering call: multi-threaded FASTA
+ * ingest, first-seen exact de-duplication and the text outputs. No GPU involved.
+ *
+ *   pangenome.py:336-405   consolidate_seqs()             -> pgx_fasta_open + pgx_fasta_write_consolidated
+ *   pangenome.py:425-450   FASTA -> sequences, .clstr out -> pgx_fasta_residues/offsets, pgx_fasta_write_clustered
+ *   pangenome.py:453-560   rename_genes_and_alleles()     -> pgx_fasta_write_clustered
+ *
+ * Reading rules are the reference's (record = line starting with '>'; header = first whitespace
+ * token minus '>'; sequence = stripped lines joined; no sequence = "missing"). Inputs its
+ * line-by-line Python semantics treat specially (carriage returns, non-ASCII or control bytes,
+ * one header naming two different sequences) are reported through info.simple = 0 with the reason in info.why: the array
+ * accessors then return NULL and the Python layer takes its own statement-by-statement path.
+ * Pointers returned by the accessors stay valid until pgx_fasta_close.
+ * ---------------------------------------------------------------------------------- */
+typedef struct pgx_fasta_set pgx_fasta_set;
+typedef struct pgx_fasta_info_t {
+    uint64_t n_records;        /* records, all files, in the order given */
+    uint64_t n_missing;        /* of those, without sequence */
+    uint64_t n_groups;         /* distinct sequences, first-seen order (the non-redundant set) */
+    uint64_t n_residue_bytes;  /* sequence bytes of the non-redundant set */
+    uint64_t n_header_bytes;
+    uint32_t simple;           /* 1: everything below is available */
+    uint32_t reserved;
+    char why[256];             /* simple == 0: what was found */
+} pgx_fasta_info_t;
+
+int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads /* 0 = all cores (<= 32) */,
+                   pgx_fasta_set **out);
+void pgx_fasta_close(pgx_fasta_set *fs);
+int pgx_fasta_info(const pgx_fasta_set *fs, pgx_fasta_info_t *out);
+const int32_t *pgx_fasta_group_of_record(const pgx_fasta_set *fs);   /* [n_records], -1 = no sequence, -2 = a
+                                                                      * sequence without a header (nameless) */
+const uint32_t *pgx_fasta_file_of_record(const pgx_fasta_set *fs);   /* [n_records] index into paths */
+const uint64_t *pgx_fasta_rep_of_group(const pgx_fasta_set *fs);     /* [n_groups] first-seen record */
+const uint8_t *pgx_fasta_residues(const pgx_fasta_set *fs);          /* the groups' sequences, concatenated: */
+const uint64_t *pgx_fasta_offsets(const pgx_fasta_set *fs);          /* [n_groups + 1]; pgx_cluster_greedy's input */
+const uint32_t *pgx_fasta_letters(const pgx_fasta_set *fs);          /* [n_groups] letters per sequence (.clstr length) */
+const uint8_t *pgx_fasta_digests(const pgx_fasta_set *fs);           /* [n_groups][32] sha256 of the sequence */
+const char *pgx_fasta_header_blob(const pgx_fasta_set *fs);          /* the records' headers, concatenated: */
+const uint64_t *pgx_fasta_header_offsets(const pgx_fasta_set *fs);   /* [n_records + 1] */
+/* consolidate_seqs()'s files: non-redundant FASTA, groups with several headers, headers without sequence */
+int pgx_fasta_write_consolidated(const pgx_fasta_set *fs, const char *nr_path, const char *shared_path,
+                                 const char *missing_path /* may be NULL */);
+/* after pgx_cluster_greedy on (residues, offsets): cd-hit's .clstr, the allele name table
+ * (<prefix><cluster><variant><member> TAB header TAB synonyms) and the non-redundant FASTA with the
+ * allele names as headers (unclustered records dropped). NULL paths are skipped. */
+int pgx_fasta_write_clustered(const pgx_fasta_set *fs, const int32_t *cluster, const int32_t *member,
+                              const float *identity, const uint8_t *strand /* may be NULL */, int nucleotide,
+                              const char *prefix, const char *variant, const char *clstr_path,
+                              const char *names_path, const char *nr_out_path);
+
 #ifdef __cplusplus
 }
 #endif

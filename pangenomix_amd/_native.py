@@ -52,9 +52,30 @@ class ClusterStats(C.Structure):
         return d
 
 
+class FastaInfo(C.Structure):
+    _fields_ = [('n_records', C.c_uint64), ('n_missing', C.c_uint64), ('n_groups', C.c_uint64),
+                ('n_residue_bytes', C.c_uint64), ('n_header_bytes', C.c_uint64), ('simple', C.c_uint32),
+                ('reserved', C.c_uint32), ('why', C.c_char * 256)]
+
+
 # every symbol include/pgx.h declares: (restype, argtypes)
 _P = C.c_void_p
+_S = C.c_char_p
 SIGNATURES = {
+    'pgx_fasta_open': (C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(_P)]),
+    'pgx_fasta_close': (None, [_P]),
+    'pgx_fasta_info': (C.c_int, [_P, C.POINTER(FastaInfo)]),
+    'pgx_fasta_group_of_record': (_P, [_P]),
+    'pgx_fasta_file_of_record': (_P, [_P]),
+    'pgx_fasta_rep_of_group': (_P, [_P]),
+    'pgx_fasta_residues': (_P, [_P]),
+    'pgx_fasta_offsets': (_P, [_P]),
+    'pgx_fasta_letters': (_P, [_P]),
+    'pgx_fasta_digests': (_P, [_P]),
+    'pgx_fasta_header_blob': (_P, [_P]),
+    'pgx_fasta_header_offsets': (_P, [_P]),
+    'pgx_fasta_write_consolidated': (C.c_int, [_P, _S, _S, _S]),
+    'pgx_fasta_write_clustered': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _S, _S, _S, _S, _S]),
     'pgx_version': (C.c_int, []),
     'pgx_last_error': (C.c_char_p, []),
     'pgx_ctx_create': (C.c_int, [C.c_int, C.POINTER(_P)]),
@@ -273,6 +294,75 @@ class Context(object):
                                            _ptr(out_identity), _ptr(out_strand), C.byref(n_clusters),
                                            C.byref(stats), stream))
         return out_cluster, out_member, out_identity, out_strand, int(n_clusters.value), stats.as_dict()
+
+
+class FastaSet(object):
+    """Genome FASTA files parsed, hashed and de-duplicated by libpgx's host side (csrc/ingest.cpp):
+    what consolidate_seqs() (reference pangenome.py:336-405) computes, as arrays. `simple` is False
+    when the files hold something the reference's line-by-line semantics treat specially (see
+    pgx.h); the arrays are then unavailable and the caller takes the Python path."""
+
+    def __init__(self, paths, threads=0):
+        self._h = C.c_void_p()
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        check(lib().pgx_fasta_open(arr, len(paths), int(threads), C.byref(self._h)))
+        info = FastaInfo()
+        check(lib().pgx_fasta_info(self._h, C.byref(info)))
+        self.n_records, self.n_missing, self.n_groups = int(info.n_records), int(info.n_missing), int(info.n_groups)
+        self.simple, self.why = bool(info.simple), info.why.decode('utf-8', 'replace')
+        self._n_res, self._n_hdr = int(info.n_residue_bytes), int(info.n_header_bytes)
+
+    def close(self):
+        if self._h:
+            lib().pgx_fasta_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _view(self, fn, dtype, n):
+        """numpy view (no copy) of one of the library's arrays; valid until close()."""
+        ptr = getattr(lib(), fn)(self._h)
+        if not ptr or n == 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=n)
+
+    group_of_record = property(lambda self: self._view('pgx_fasta_group_of_record', np.int32, self.n_records))
+    file_of_record = property(lambda self: self._view('pgx_fasta_file_of_record', np.uint32, self.n_records))
+    rep_of_group = property(lambda self: self._view('pgx_fasta_rep_of_group', np.uint64, self.n_groups))
+    residues = property(lambda self: self._view('pgx_fasta_residues', np.uint8, self._n_res))
+    offsets = property(lambda self: self._view('pgx_fasta_offsets', np.uint64, self.n_groups + 1))
+    letters = property(lambda self: self._view('pgx_fasta_letters', np.uint32, self.n_groups))
+    digests = property(lambda self: self._view('pgx_fasta_digests', np.uint8, self.n_groups * 32))
+    header_offsets = property(lambda self: self._view('pgx_fasta_header_offsets', np.uint64, self.n_records + 1))
+
+    def headers(self, records=None):
+        """Header strings of all records (or of the given record indices)."""
+        blob = bytes(self._view('pgx_fasta_header_blob', np.uint8, self._n_hdr))
+        off = self.header_offsets
+        idx = range(self.n_records) if records is None else records
+        return [blob[off[i]:off[i + 1]].decode('ascii') for i in idx]
+
+    def write_consolidated(self, nr_path, shared_path, missing_path=None):
+        check(lib().pgx_fasta_write_consolidated(self._h, os.fsencode(nr_path), os.fsencode(shared_path),
+                                                 os.fsencode(missing_path) if missing_path else None))
+
+    def write_clustered(self, cluster, member, identity, strand, nucleotide, prefix, variant,
+                        clstr_path=None, names_path=None, nr_out_path=None):
+        cluster = np.ascontiguousarray(cluster, dtype=np.int32)
+        member = np.ascontiguousarray(member, dtype=np.int32)
+        identity = np.ascontiguousarray(identity, dtype=np.float32)
+        strand = None if strand is None else np.ascontiguousarray(strand, dtype=np.uint8)
+        if not (cluster.size == member.size == identity.size == self.n_groups):
+            raise ValueError('one entry per non-redundant sequence expected')
+        enc = lambda x: os.fsencode(x) if x else None   # noqa: E731
+        check(lib().pgx_fasta_write_clustered(self._h, _ptr(cluster), _ptr(member), _ptr(identity), _ptr(strand),
+                                              1 if nucleotide else 0, prefix.encode(), variant.encode(),
+                                              enc(clstr_path), enc(names_path), enc(nr_out_path)))
 
 
 _default_ctx = None

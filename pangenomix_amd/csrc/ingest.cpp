@@ -1,0 +1,546 @@
+// libpgx host side: multi-threaded FASTA ingest, exact de-duplication and the text outputs around the
+// clustering call. No GPU work here; plain C++ behind the same C ABI (include/pgx.h).
+//
+// What it replaces in the reference (AnnaLew/pangenomix, pure Python, one line at a time):
+//   pangenome.py:336-405   consolidate_seqs(): merge genome FASTA files, first-seen exact de-duplication
+//                          by sha256 of the joined sequence lines, nr FASTA + redundant/missing header files
+//   pangenome.py:425-450   the FASTA -> arrays step of the clustering boundary and cd-hit's .clstr writer
+//   pangenome.py:453-560   rename_genes_and_alleles(): <name>_C#A# names, the name table, the renamed nr FASTA
+// The reading rules are the reference's own (a record starts at a line whose first character is '>';
+// header = first whitespace token minus '>'; sequence lines are stripped and joined; a record without
+// sequence is "missing"). Inputs the line-by-line Python semantics treat specially -- carriage returns,
+// non-ASCII or unusual control bytes, one header naming two different sequences -- are REPORTED (info.simple = 0), not guessed at: the Python layer then
+// takes its own slow path, which mirrors the reference statement by statement. Two oddities ARE handled,
+// because the reference's own fixtures hold them: sequence text before the first header and a record whose
+// header is empty both count as one record without a name (skipped by consolidate_seqs, :384; reported as
+// 'MISSING: ' by build_genetic_feature_tables, :652): group -2.
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pgx.h"
+
+void pgx_set_error(const char *fmt, ...);
+
+namespace {
+
+// ---- SHA-256 (FIPS 180-4), the reference's de-duplication key (pangenome.py:2057-2059) ----------------
+const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+void sha256_block_plain(uint32_t st[8], const uint8_t *p) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; ++i) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; ++i) {
+        const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int i = 0; i < 64; ++i) {
+        const uint32_t t1 = h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i];
+        const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+}
+#if defined(__x86_64__)
+// the same compression function on the SHA extensions (x86 SHA-NI), used when the CPU has them
+__attribute__((target("sha,sse4.1,ssse3"))) void sha256_block_ni(uint32_t st[8], const uint8_t *p) {
+    const __m128i mask = _mm_set_epi64x(0x0c0d0e0f08090a0bLL, 0x0405060700010203LL);
+    __m128i tmp = _mm_loadu_si128((const __m128i *)&st[0]);
+    __m128i s1 = _mm_loadu_si128((const __m128i *)&st[4]);
+    tmp = _mm_shuffle_epi32(tmp, 0xB1);            // CDAB
+    s1 = _mm_shuffle_epi32(s1, 0x1B);              // EFGH
+    __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);      // ABEF
+    s1 = _mm_blend_epi16(s1, tmp, 0xF0);           // CDGH
+    const __m128i save0 = s0, save1 = s1;
+    __m128i m[4];
+    for (int i = 0; i < 16; ++i) {
+        if (i < 4) m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(p + 16 * i)), mask);
+        else {
+            __m128i x = _mm_sha256msg1_epu32(m[i & 3], m[(i + 1) & 3]);                 // W[t-16..] + s0(W[t-15..])
+            x = _mm_add_epi32(x, _mm_alignr_epi8(m[(i + 3) & 3], m[(i + 2) & 3], 4));   // + W[t-7..]
+            m[i & 3] = _mm_sha256msg2_epu32(x, m[(i + 3) & 3]);                         // + s1(W[t-2..])
+        }
+        __m128i msg = _mm_add_epi32(m[i & 3], _mm_loadu_si128((const __m128i *)&K256[4 * i]));
+        s1 = _mm_sha256rnds2_epu32(s1, s0, msg);
+        msg = _mm_shuffle_epi32(msg, 0x0E);
+        s0 = _mm_sha256rnds2_epu32(s0, s1, msg);
+    }
+    s0 = _mm_add_epi32(s0, save0);
+    s1 = _mm_add_epi32(s1, save1);
+    tmp = _mm_shuffle_epi32(s0, 0x1B);             // FEBA
+    s1 = _mm_shuffle_epi32(s1, 0xB1);              // DCHG
+    s0 = _mm_blend_epi16(tmp, s1, 0xF0);           // DCBA
+    s1 = _mm_alignr_epi8(s1, tmp, 8);              // HGFE
+    _mm_storeu_si128((__m128i *)&st[0], s0);
+    _mm_storeu_si128((__m128i *)&st[4], s1);
+}
+const bool kHaveShaNi = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1");
+#else
+inline void sha256_block_ni(uint32_t *, const uint8_t *) {}
+const bool kHaveShaNi = false;
+#endif
+void sha256(const uint8_t *data, size_t n, uint8_t out[32]) {
+    uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    const auto sha256_block = kHaveShaNi ? sha256_block_ni : sha256_block_plain;
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) sha256_block(st, data + i);
+    uint8_t tail[128] = {0};
+    const size_t rem = n - i;
+    memcpy(tail, data + i, rem);
+    tail[rem] = 0x80;
+    const size_t tl = rem + 1 + 8 <= 64 ? 64 : 128;
+    const uint64_t bits = (uint64_t)n * 8;
+    for (int k = 0; k < 8; ++k) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    sha256_block(st, tail);
+    if (tl == 128) sha256_block(st, tail + 64);
+    for (int k = 0; k < 8; ++k) { out[4 * k] = st[k] >> 24; out[4 * k + 1] = st[k] >> 16; out[4 * k + 2] = st[k] >> 8; out[4 * k + 3] = st[k]; }
+}
+
+struct Rec {
+    uint32_t file;
+    uint32_t hdr_len;
+    uint64_t hdr_off;      // in the file: header token (after '>')
+    uint64_t body_off;     // in the file: the lines after the header line
+    uint64_t body_len;     // raw span up to the next record (valid when raw_ok)
+    uint64_t seq_off;      // in the file's sequence arena: stripped lines joined
+    uint32_t seq_len;
+    uint32_t letters;      // [A-Za-z] in the sequence: the length cd-hit's reader keeps
+    int32_t body_alt;      // >= 0: index of the normalised body ('\n'.join(stripped lines) + '\n') in the file's alt list
+};
+
+struct FileData {
+    const char *map = nullptr;
+    size_t size = 0;
+    std::vector<Rec> recs;
+    std::vector<uint8_t> seq;          // sequences of this file's records, concatenated
+    std::vector<std::string> alt;      // normalised bodies of the records whose raw text differs
+    std::vector<uint8_t> digest;       // 32 bytes per record
+    bool simple = true;
+    std::string why;
+};
+
+inline bool is_blank(char c) { return c == ' ' || c == '\t'; }
+
+void parse_file(FileData &F, uint32_t file_id) {
+    const char *p = F.map;
+    const size_t n = F.size;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = (unsigned char)p[i];
+        if (c == '\r' || c >= 0x80 || (c < 0x20 && c != '\n' && c != '\t')) {
+            F.simple = false;
+            F.why = c == '\r' ? "carriage returns" : "non-ASCII or control bytes";
+            return;
+        }
+    }
+    F.seq.reserve(n);
+    size_t pos = 0;
+    Rec cur{};          // (the lines before the first header form a record without a name)
+    cur.file = file_id; cur.body_alt = -1;
+    bool raw_ok = true;
+    std::string alt;
+    auto close_record = [&](size_t end) {
+        cur.body_len = end - cur.body_off;
+        cur.seq_len = (uint32_t)(F.seq.size() - cur.seq_off);
+        if (cur.hdr_len == 0 && cur.seq_len == 0) return;         // nameless and empty: nobody ever sees it
+        if (cur.body_len && p[end - 1] != '\n') raw_ok = false;   // last line of the file without a newline
+        if (!raw_ok) { cur.body_alt = (int32_t)F.alt.size(); F.alt.push_back(alt); }
+        F.recs.push_back(cur);
+    };
+    while (pos < n) {
+        const char *nl = (const char *)memchr(p + pos, '\n', n - pos);
+        const size_t eol = nl ? (size_t)(nl - p) : n;      // line = [pos, eol)
+        const size_t next = nl ? eol + 1 : n;
+        if (p[pos] == '>') {
+            close_record(pos);
+            size_t e = pos + 1;
+            while (e < eol && !is_blank(p[e])) ++e;
+            cur = Rec{};
+            cur.file = file_id; cur.hdr_off = pos + 1; cur.hdr_len = (uint32_t)(e - pos - 1);
+            cur.body_off = next; cur.seq_off = F.seq.size(); cur.body_alt = -1;
+            raw_ok = true; alt.clear();
+        } else {
+            size_t a = pos, b = eol;
+            while (a < b && is_blank(p[a])) ++a;
+            while (b > a && is_blank(p[b - 1])) --b;
+            if (a != pos || b != eol) raw_ok = false;
+            alt.append(p + a, b - a); alt.push_back('\n');
+            for (size_t i = a; i < b; ++i) cur.letters += (unsigned)((p[i] | 0x20) - 'a') < 26u;
+            F.seq.insert(F.seq.end(), (const uint8_t *)p + a, (const uint8_t *)p + b);
+        }
+        pos = next;
+    }
+    close_record(n);
+    F.digest.resize(F.recs.size() * 32);
+    for (size_t r = 0; r < F.recs.size(); ++r)
+        if (F.recs[r].seq_len) sha256(F.seq.data() + F.recs[r].seq_off, F.recs[r].seq_len, &F.digest[r * 32]);
+}
+
+template <typename F>
+void parallel_for(size_t n, int threads, F f) {
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); };
+    std::vector<std::thread> pool;
+    const int t = std::max(1, std::min<int>(threads, (int)n));
+    for (int k = 1; k < t; ++k) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+}
+
+struct Out {   // buffered file writer
+    FILE *f = nullptr;
+    std::vector<char> buf;
+    explicit Out(const char *path) { f = fopen(path, "w"); buf.reserve(1 << 22); }
+    ~Out() { close(); }
+    bool ok() const { return f != nullptr; }
+    void put(const char *p, size_t n) {
+        if (buf.size() + n > buf.capacity()) flush();
+        if (n > buf.capacity()) { fwrite(p, 1, n, f); return; }
+        buf.insert(buf.end(), p, p + n);
+    }
+    void put(const std::string &s) { put(s.data(), s.size()); }
+    void put(char c) { put(&c, 1); }
+    void flush() { if (f && !buf.empty()) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } }
+    bool close() { if (!f) return true; flush(); const bool good = fclose(f) == 0; f = nullptr; return good; }
+};
+
+}  // namespace
+
+struct pgx_fasta_set {
+    std::vector<std::string> paths;
+    std::vector<FileData> files;
+    std::vector<uint64_t> first_rec;          // per file: index of its first record in the global order
+    uint64_t n_records = 0, n_missing = 0, n_groups = 0;
+    std::vector<int32_t> group_of;            // per record, -1 = no sequence
+    std::vector<uint32_t> file_of;            // per record
+    std::vector<uint64_t> rep_of_group;       // first-seen record of the group
+    std::vector<uint64_t> hdr_off;            // header blob offsets, n_records + 1
+    std::string hdr_blob;
+    std::vector<uint8_t> residues;            // groups' sequences, first-seen order
+    std::vector<uint64_t> offsets;            // n_groups + 1
+    std::vector<uint32_t> letters;            // per group
+    std::vector<uint8_t> digests;             // per group, 32 bytes
+    std::vector<uint64_t> members_off;        // per group: its records, encounter order (CSR)
+    std::vector<uint64_t> members;
+    bool simple = true;
+    std::string why;
+    const Rec &rec(uint64_t r) const {
+        const size_t f = file_of[r];
+        return files[f].recs[r - first_rec[f]];
+    }
+    ~pgx_fasta_set() {
+        for (auto &F : files) if (F.map && F.size) munmap((void *)F.map, F.size);
+    }
+};
+
+extern "C" {
+
+int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pgx_fasta_set **out) {
+    if (!out || (n_paths && !paths)) { pgx_set_error("pgx_fasta_open: NULL argument"); return PGX_ERR_INVALID; }
+    *out = nullptr;
+    auto *S = new (std::nothrow) pgx_fasta_set();
+    if (!S) { pgx_set_error("pgx_fasta_open: out of memory"); return PGX_ERR_NOMEM; }
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    S->files.resize(n_paths);
+    for (uint32_t i = 0; i < n_paths; ++i) S->paths.emplace_back(paths[i]);
+    const bool trace = std::getenv("PGX_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pgx] ingest: %-28s %8.2f ms\n", what, 1e3 * std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
+    std::atomic<int> failed{-1};
+    parallel_for(n_paths, n_threads, [&](size_t i) {
+        FileData &F = S->files[i];
+        const int fd = open(S->paths[i].c_str(), O_RDONLY);
+        struct stat sb;
+        if (fd < 0 || fstat(fd, &sb) != 0) { failed = (int)i; if (fd >= 0) close(fd); return; }
+        F.size = (size_t)sb.st_size;
+        if (F.size) {
+            void *m = mmap(nullptr, F.size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { failed = (int)i; F.size = 0; close(fd); return; }
+            F.map = (const char *)m;
+            madvise(m, F.size, MADV_SEQUENTIAL);
+        }
+        close(fd);
+        parse_file(F, (uint32_t)i);
+    });
+    if (failed >= 0) {
+        pgx_set_error("pgx_fasta_open: cannot read %s", S->paths[(size_t)failed].c_str());
+        delete S;
+        return PGX_ERR_INVALID;
+    }
+    lap("read + parse + sha256");
+    S->first_rec.resize(n_paths + 1, 0);
+    for (uint32_t i = 0; i < n_paths; ++i) {
+        if (!S->files[i].simple && S->simple) { S->simple = false; S->why = S->paths[i] + ": " + S->files[i].why; }
+        S->first_rec[i + 1] = S->first_rec[i] + S->files[i].recs.size();
+    }
+    S->n_records = S->first_rec[n_paths];
+    if (!S->simple) { *out = S; return PGX_OK; }   // the caller takes its own path; nothing else is built
+    const uint64_t R = S->n_records;
+    S->group_of.assign(R, -1);
+    S->file_of.resize(R);
+    S->hdr_off.resize(R + 1);
+    uint64_t hb = 0;
+    for (uint32_t i = 0; i < n_paths; ++i)
+        for (size_t r = 0; r < S->files[i].recs.size(); ++r) {
+            const uint64_t g = S->first_rec[i] + r;
+            S->file_of[g] = i;
+            S->hdr_off[g] = hb;
+            hb += S->files[i].recs[r].hdr_len;
+        }
+    S->hdr_off[R] = hb;
+    S->hdr_blob.resize(hb);
+    parallel_for(n_paths, n_threads, [&](size_t i) {
+        const FileData &F = S->files[i];
+        for (size_t r = 0; r < F.recs.size(); ++r)
+            memcpy(&S->hdr_blob[S->hdr_off[S->first_rec[i] + r]], F.map + F.recs[r].hdr_off, F.recs[r].hdr_len);
+    });
+    lap("headers");
+    // first-seen exact de-duplication, in the order given (files, then records): open addressing on the
+    // digest's first 8 bytes, full 32-byte compare
+    size_t cap = 16;
+    while (cap < 2 * (size_t)R + 16) cap <<= 1;
+    std::vector<int64_t> table(cap, -1);   // -> group
+    for (uint64_t g = 0; g < R; ++g) {
+        const Rec &rc = S->rec(g);
+        if (!rc.hdr_len) { S->group_of[g] = -2; continue; }      // a sequence without a name
+        if (!rc.seq_len) { ++S->n_missing; continue; }
+        const uint8_t *d = &S->files[rc.file].digest[(g - S->first_rec[rc.file]) * 32];
+        uint64_t h;
+        memcpy(&h, d, 8);
+        size_t slot = (size_t)(h * 0x9E3779B97F4A7C15ull) & (cap - 1);
+        for (;;) {
+            const int64_t t = table[slot];
+            if (t < 0) {
+                table[slot] = (int64_t)S->rep_of_group.size();
+                S->group_of[g] = (int32_t)S->rep_of_group.size();
+                S->rep_of_group.push_back(g);
+                S->digests.insert(S->digests.end(), d, d + 32);
+                break;
+            }
+            if (memcmp(&S->digests[(size_t)t * 32], d, 32) == 0) { S->group_of[g] = (int32_t)t; break; }
+            slot = (slot + 1) & (cap - 1);
+        }
+    }
+    S->n_groups = S->rep_of_group.size();
+    const uint64_t G = S->n_groups;
+    lap("de-duplication");
+    // the groups' members in encounter order (CSR) and the sequences handed to the clustering call
+    S->members_off.assign(G + 1, 0);
+    for (uint64_t g = 0; g < R; ++g) if (S->group_of[g] >= 0) S->members_off[(size_t)S->group_of[g] + 1]++;
+    for (uint64_t k = 0; k < G; ++k) S->members_off[k + 1] += S->members_off[k];
+    S->members.resize(S->members_off[G]);
+    {
+        std::vector<uint64_t> fill(S->members_off.begin(), S->members_off.end() - 1);
+        for (uint64_t g = 0; g < R; ++g) if (S->group_of[g] >= 0) S->members[fill[(size_t)S->group_of[g]]++] = g;
+    }
+    S->offsets.resize(G + 1);
+    S->letters.resize(G);
+    uint64_t tot = 0;
+    for (uint64_t k = 0; k < G; ++k) {
+        const Rec &rc = S->rec(S->rep_of_group[k]);
+        S->offsets[k] = tot; tot += rc.seq_len; S->letters[k] = rc.letters;
+    }
+    S->offsets[G] = tot;
+    S->residues.resize(tot + 16);
+    parallel_for((size_t)((G + 4095) / 4096), n_threads, [&](size_t c) {
+        for (uint64_t k = c * 4096; k < std::min<uint64_t>(G, (c + 1) * 4096); ++k) {
+            const Rec &rc = S->rec(S->rep_of_group[k]);
+            memcpy(&S->residues[S->offsets[k]], S->files[rc.file].seq.data() + rc.seq_off, rc.seq_len);
+        }
+    });
+    lap("groups + sequences");
+    // one header, one group: the reference maps records to alleles through a dictionary keyed by the header
+    // string (pangenome.py:505-521, :649); a header that names two different sequences is resolved there by
+    // insertion order. Such inputs are left to the Python path.
+    {
+        size_t hc = 16;
+        while (hc < 2 * (size_t)R + 16) hc <<= 1;
+        std::vector<int64_t> ht(hc, -1);   // -> a record with that header
+        for (uint64_t g = 0; g < R && S->simple; ++g) {
+            if (S->group_of[g] < 0) continue;
+            const char *h = &S->hdr_blob[S->hdr_off[g]];
+            const size_t hl = (size_t)(S->hdr_off[g + 1] - S->hdr_off[g]);
+            uint64_t x = 1469598103934665603ull;
+            for (size_t i = 0; i < hl; ++i) x = (x ^ (unsigned char)h[i]) * 1099511628211ull;
+            size_t slot = (size_t)(x * 0x9E3779B97F4A7C15ull) & (hc - 1);
+            for (;;) {
+                const int64_t t = ht[slot];
+                if (t < 0) { ht[slot] = (int64_t)g; break; }
+                const size_t tl = (size_t)(S->hdr_off[t + 1] - S->hdr_off[t]);
+                if (tl == hl && memcmp(&S->hdr_blob[S->hdr_off[t]], h, hl) == 0) {
+                    if (S->group_of[t] != S->group_of[g]) { S->simple = false; S->why = "header '" + std::string(h, hl) + "' names two different sequences"; }
+                    break;
+                }
+                slot = (slot + 1) & (hc - 1);
+            }
+        }
+    }
+    lap("header check");
+    *out = S;
+    return PGX_OK;
+}
+
+void pgx_fasta_close(pgx_fasta_set *S) { delete S; }
+
+int pgx_fasta_info(const pgx_fasta_set *S, pgx_fasta_info_t *out) {
+    if (!S || !out) { pgx_set_error("pgx_fasta_info: NULL argument"); return PGX_ERR_INVALID; }
+    memset(out, 0, sizeof(*out));
+    out->n_records = S->n_records; out->n_missing = S->n_missing; out->n_groups = S->n_groups;
+    out->n_residue_bytes = S->offsets.empty() ? 0 : S->offsets.back();
+    out->n_header_bytes = S->hdr_blob.size();
+    out->simple = S->simple ? 1 : 0;
+    snprintf(out->why, sizeof(out->why), "%s", S->why.c_str());
+    return PGX_OK;
+}
+
+const int32_t *pgx_fasta_group_of_record(const pgx_fasta_set *S) { return S && S->simple ? S->group_of.data() : nullptr; }
+const uint32_t *pgx_fasta_file_of_record(const pgx_fasta_set *S) { return S && S->simple ? S->file_of.data() : nullptr; }
+const uint64_t *pgx_fasta_rep_of_group(const pgx_fasta_set *S) { return S && S->simple ? S->rep_of_group.data() : nullptr; }
+const uint8_t *pgx_fasta_residues(const pgx_fasta_set *S) { return S && S->simple ? S->residues.data() : nullptr; }
+const uint64_t *pgx_fasta_offsets(const pgx_fasta_set *S) { return S && S->simple ? S->offsets.data() : nullptr; }
+const uint32_t *pgx_fasta_letters(const pgx_fasta_set *S) { return S && S->simple ? S->letters.data() : nullptr; }
+const uint8_t *pgx_fasta_digests(const pgx_fasta_set *S) { return S && S->simple ? S->digests.data() : nullptr; }
+const char *pgx_fasta_header_blob(const pgx_fasta_set *S) { return S && S->simple ? S->hdr_blob.data() : nullptr; }
+const uint64_t *pgx_fasta_header_offsets(const pgx_fasta_set *S) { return S && S->simple ? S->hdr_off.data() : nullptr; }
+
+static void put_body(Out &o, const pgx_fasta_set *S, const Rec &rc) {
+    const FileData &F = S->files[rc.file];
+    if (rc.body_alt >= 0) o.put(F.alt[(size_t)rc.body_alt]);
+    else o.put(F.map + rc.body_off, rc.body_len);
+}
+static void put_header(Out &o, const pgx_fasta_set *S, uint64_t r) {
+    o.put(&S->hdr_blob[S->hdr_off[r]], (size_t)(S->hdr_off[r + 1] - S->hdr_off[r]));
+}
+
+// consolidate_seqs()'s three files (pangenome.py:374-403): the non-redundant FASTA (first-seen records, the
+// stripped sequence lines as they were wrapped), the groups with more than one header (encounter order,
+// tab-separated), the headers without sequence.
+int pgx_fasta_write_consolidated(const pgx_fasta_set *S, const char *nr_path, const char *shared_path,
+                                 const char *missing_path) {
+    if (!S || !S->simple || !nr_path || !shared_path) { pgx_set_error("pgx_fasta_write_consolidated: invalid argument"); return PGX_ERR_INVALID; }
+    {
+        Out o(nr_path);
+        if (!o.ok()) { pgx_set_error("cannot write %s", nr_path); return PGX_ERR_INVALID; }
+        for (uint64_t k = 0; k < S->n_groups; ++k) {
+            const uint64_t r = S->rep_of_group[k];
+            o.put('>'); put_header(o, S, r); o.put('\n');
+            put_body(o, S, S->rec(r));
+        }
+        if (!o.close()) { pgx_set_error("write to %s failed", nr_path); return PGX_ERR_INVALID; }
+    }
+    {
+        Out o(shared_path);
+        if (!o.ok()) { pgx_set_error("cannot write %s", shared_path); return PGX_ERR_INVALID; }
+        for (uint64_t k = 0; k < S->n_groups; ++k) {
+            const uint64_t a = S->members_off[k], b = S->members_off[k + 1];
+            if (b - a < 2) continue;
+            for (uint64_t i = a; i < b; ++i) { if (i > a) o.put('\t'); put_header(o, S, S->members[i]); }
+            o.put('\n');
+        }
+        if (!o.close()) { pgx_set_error("write to %s failed", shared_path); return PGX_ERR_INVALID; }
+    }
+    if (missing_path) {
+        Out o(missing_path);
+        if (!o.ok()) { pgx_set_error("cannot write %s", missing_path); return PGX_ERR_INVALID; }
+        for (uint64_t r = 0; r < S->n_records; ++r)
+            if (S->group_of[r] == -1) { put_header(o, S, r); o.put('\n'); }
+        if (!o.close()) { pgx_set_error("write to %s failed", missing_path); return PGX_ERR_INVALID; }
+    }
+    return PGX_OK;
+}
+
+// What follows the clustering call, as text (pangenome.py:444-450 -> cd-hit's .clstr; :505-544): for the
+// groups' sequences in first-seen order, cluster[k] / member[k] / identity[k] / strand[k] as pgx_cluster_greedy
+// returns them.
+//   clstr_path   cd-hit's grammar: clusters in creation order, members in member order
+//   names_path   <prefix><cluster><variant><member> \t header \t synonyms...   in .clstr order
+//   nr_out_path  the non-redundant FASTA again with the allele names as headers; unclustered records dropped
+// NULL paths are skipped.
+int pgx_fasta_write_clustered(const pgx_fasta_set *S, const int32_t *cluster, const int32_t *member,
+                              const float *identity, const uint8_t *strand, int nucleotide, const char *prefix,
+                              const char *variant, const char *clstr_path, const char *names_path,
+                              const char *nr_out_path) {
+    if (!S || !S->simple || !cluster || !member || !identity || !prefix || !variant) {
+        pgx_set_error("pgx_fasta_write_clustered: invalid argument");
+        return PGX_ERR_INVALID;
+    }
+    const uint64_t G = S->n_groups;
+    std::vector<uint64_t> order;
+    order.reserve(G);
+    for (uint64_t k = 0; k < G; ++k) if (cluster[k] >= 0) order.push_back(k);
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+        return cluster[a] != cluster[b] ? cluster[a] < cluster[b] : (member[a] != member[b] ? member[a] < member[b] : a < b);
+    });
+    char num[96];
+    if (clstr_path) {
+        Out o(clstr_path);
+        if (!o.ok()) { pgx_set_error("cannot write %s", clstr_path); return PGX_ERR_INVALID; }
+        int32_t last = -1;
+        for (uint64_t k : order) {
+            if (cluster[k] != last) { last = cluster[k]; o.put(num, (size_t)snprintf(num, sizeof num, ">Cluster %d\n", last)); }
+            o.put(num, (size_t)snprintf(num, sizeof num, "%d\t%u%s, >", member[k], S->letters[k], nucleotide ? "nt" : "aa"));
+            put_header(o, S, S->rep_of_group[k]);
+            if (member[k] == 0) o.put("... *\n", 6);
+            else {
+                const float pct = identity[k] * 100.0f;
+                if (nucleotide) o.put(num, (size_t)snprintf(num, sizeof num, "... at %c/%.2f%%\n", strand && strand[k] ? '-' : '+', (double)pct));
+                else o.put(num, (size_t)snprintf(num, sizeof num, "... at %.2f%%\n", (double)pct));
+            }
+        }
+        if (!o.close()) { pgx_set_error("write to %s failed", clstr_path); return PGX_ERR_INVALID; }
+    }
+    auto put_name = [&](Out &o, uint64_t k) {
+        o.put(prefix, strlen(prefix));
+        o.put(num, (size_t)snprintf(num, sizeof num, "%d%s%d", cluster[k], variant, member[k]));
+    };
+    if (names_path) {
+        Out o(names_path);
+        if (!o.ok()) { pgx_set_error("cannot write %s", names_path); return PGX_ERR_INVALID; }
+        for (uint64_t k : order) {
+            put_name(o, k);
+            for (uint64_t i = S->members_off[k]; i < S->members_off[k + 1]; ++i) { o.put('\t'); put_header(o, S, S->members[i]); }
+            o.put('\n');
+        }
+        if (!o.close()) { pgx_set_error("write to %s failed", names_path); return PGX_ERR_INVALID; }
+    }
+    if (nr_out_path) {
+        Out o(nr_out_path);
+        if (!o.ok()) { pgx_set_error("cannot write %s", nr_out_path); return PGX_ERR_INVALID; }
+        for (uint64_t k = 0; k < G; ++k) {
+            if (cluster[k] < 0) continue;
+            o.put('>'); put_name(o, k); o.put('\n');
+            put_body(o, S, S->rec(S->rep_of_group[k]));
+        }
+        if (!o.close()) { pgx_set_error("write to %s failed", nr_out_path); return PGX_ERR_INVALID; }
+    }
+    return PGX_OK;
+}
+
+}  // extern "C"

@@ -391,6 +391,107 @@ def extract_noncoding(genome_gff, genome_fna, noncoding_out, flanking=(0, 0),
 
 
 # ---------------------------------------------------------------------------
+# the same pipeline on libpgx's host side: consolidate -> cluster -> name -> tables
+# ---------------------------------------------------------------------------
+def _lex_key(values, shorter_first):
+    """Sort key under which non-negative integers order like their decimal strings do inside an
+    allele name: digit by digit, and where one string ends the other continues with a digit, the
+    shorter one sorts first (`shorter_first`: the name ends there) or last (the cluster number is
+    followed by the variant letter 'A', which sorts after every digit: C100 < C10 < C1, reference
+    :615)."""
+    v = np.asarray(values, dtype=np.int64)
+    nd = np.ones(v.shape, dtype=np.int64)
+    for p in range(1, 10):
+        nd += v >= 10 ** p
+    key = np.zeros(v.shape, dtype=np.int64)
+    pad = 0 if shorter_first else 11
+    for p in range(10):
+        digit = (v // 10 ** np.maximum(nd - 1 - p, 0)) % 10 + 1
+        key = key * 12 + np.where(p < nd, digit, pad)
+    return key
+
+
+def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, cluster_type, cdhit_args,
+                     fastasort_path, cluster_fn=None):
+    """consolidate_seqs -> cluster_with_cdhit -> rename_genes_and_alleles -> build_genetic_feature_tables
+    with the file work in libpgx's multi-threaded host code (csrc/ingest.cpp) and the tables from
+    arrays instead of per-record dictionaries: the same files, byte for byte, and the same LSDFs as the
+    step-by-step functions above (tests/test_host_golden.py pins both against the reference's output).
+    Returns None when the fast path does not apply -- inputs the reference's line-by-line semantics
+    treat specially (see pgx.h), duplicate genome names, an external fastasort, a multi-process group:
+    the caller then runs the step-by-step functions. `cluster_fn(residues, offsets, params)` replaces the
+    GPU clustering call in tests (the CPU oracle, or a reader of a given .clstr)."""
+    from . import _native, cluster
+    genomes = [__get_genome_from_filename__(p) for p in genome_paths]
+    if fastasort_path or cluster._group is not None or len(set(genomes)) != len(genomes):
+        return None
+    fs = _native.FastaSet(genome_paths)
+    try:
+        if not fs.simple:
+            print('Note: taking the step-by-step path (%s)' % fs.why)
+            return None
+        fs.write_consolidated(nr_fasta, shared, missing)                       # H1 (:336-405)
+        print('Headers without sequences:', fs.n_missing)
+        nucleotide = nr_fasta[-4:].lower() == '.fna'                           # K1/K2 (:425-450)
+        params = cluster.params_from_cdhit_args(cdhit_args, 'nt' if nucleotide else 'aa')
+        print('Running: libpgx greedy clustering (%s rules) -i %s -o %s -c %g -n %d' % (
+            'cd-hit-est' if nucleotide else 'cd-hit', nr_fasta, nr_fasta + '.cdhit', params.identity, params.word_len))
+        cl, mem, iden, strand, n_clusters = (cluster_fn or cluster.cluster_sequences)(fs.residues, fs.offsets, params)[:5]
+        print('%9d  finished  %9d  clusters' % (int((cl >= 0).sum()), n_clusters))
+        prefix = name + '_' + CLUSTER_TYPES[cluster_type]                      # H2 (:453-560)
+        fs.write_clustered(cl, mem, iden, strand, nucleotide, prefix, VARIANT_TYPES['allele'],
+                           clstr_path=nr_fasta + '.cdhit.clstr', names_path=names_tsv, nr_out_path=nr_fasta + '.tmp')
+        os.replace(nr_fasta + '.tmp', nr_fasta)
+        unclustered = np.flatnonzero(cl < 0)
+        if unclustered.size:
+            for h in fs.headers(fs.rep_of_group[unclustered]):
+                print('MISSING:', h)
+
+        print('Loadings header-allele mappings...')                            # H4 (:563-680)
+        genome_order = sorted(genomes)
+        print('Sorting alleles...')
+        clustered = np.flatnonzero(cl >= 0)
+        order = np.lexsort((_lex_key(mem[clustered], True), _lex_key(cl[clustered], False)))
+        allele_groups = clustered[order]                       # groups in allele-row order
+        row_of_group = np.full(fs.n_groups, -1, dtype=np.int64)
+        row_of_group[allele_groups] = np.arange(allele_groups.size)
+        print('Sorting clusters...')
+        c_sorted = cl[allele_groups]
+        new_gene = np.ones(c_sorted.size, dtype=bool)
+        new_gene[1:] = c_sorted[1:] != c_sorted[:-1]
+        gene_of_allele = np.cumsum(new_gene) - 1
+        allele_order = [prefix + '%dA%d' % cm for cm in zip(c_sorted.tolist(), mem[allele_groups].tolist())]
+        gene_order = [prefix + str(c) for c in c_sorted[new_gene].tolist()]
+        print('Genomes:', len(genome_order))
+        print('Clusters:', len(gene_order))
+        print('Alleles:', len(allele_order))
+        # records in sorted(path) order, file order inside (:635); a record counts if it has a sequence (:643)
+        path_rank = np.empty(len(genome_paths), dtype=np.int64)
+        path_rank[np.argsort(np.array(genome_paths, dtype=object), kind='stable')] = np.arange(len(genome_paths))
+        genome_of_file = np.array([genome_order.index(g) for g in genomes], dtype=np.int64)
+        file_of = fs.file_of_record.astype(np.int64)
+        recs = np.argsort(path_rank[file_of], kind='stable')
+        grp = fs.group_of_record[recs]
+        seen = grp != -1                                       # (-2: a sequence without a name, 'MISSING: ' below)
+        recs, grp = recs[seen], grp[seen]
+        rows = np.where(grp >= 0, row_of_group[np.maximum(grp, 0)], -1)
+        lost = np.flatnonzero(rows < 0)
+        if lost.size:
+            for h in fs.headers(recs[lost]):
+                print('MISSING:', h)
+        keep = rows >= 0
+        rec_allele, rec_genome = rows[keep], genome_of_file[file_of[recs[keep]]]
+        print('Building binary matrix...')
+        sp_alleles = _first_occurrence_coo(rec_allele, rec_genome, len(allele_order), len(genome_order))
+        sp_genes = _first_occurrence_coo(gene_of_allele[rec_allele] if rec_allele.size else rec_allele,
+                                         rec_genome, len(gene_order), len(genome_order))
+        return (sparse_utils.LightSparseDataFrame(allele_order, genome_order, sp_alleles),
+                sparse_utils.LightSparseDataFrame(gene_order, genome_order, sp_genes))
+    finally:
+        fs.close()
+
+
+# ---------------------------------------------------------------------------
 # entry points (reference :44-156, :159-316)
 # ---------------------------------------------------------------------------
 def _check_format(output_format):
@@ -414,18 +515,23 @@ def build_cds_pangenome(genome_faa_paths, output_dir, name='Test',
     nr_faa = _p(output_dir, name, '_nr.faa')
     shared = _p(output_dir, name, '_redundant_headers.tsv')
     missing = _p(output_dir, name, '_missing_headers.txt')
-    consolidate_seqs(genome_faa_paths, nr_faa, shared, missing)
+    fast = _native_pipeline(genome_faa_paths, nr_faa, shared, missing, _p(output_dir, name, '_allele_names.tsv'),
+                            name, 'cds', cdhit_args, fastasort_path) if output_format == 'lsdf' else None
+    if fast is not None:
+        df_alleles, df_genes = fast
+    else:
+        consolidate_seqs(genome_faa_paths, nr_faa, shared, missing)
 
-    cluster_with_cdhit(nr_faa, nr_faa + '.cdhit', cdhit_args)
-    os.remove(nr_faa + '.cdhit')
-    clstr = nr_faa + '.cdhit.clstr'
+        cluster_with_cdhit(nr_faa, nr_faa + '.cdhit', cdhit_args)
+        os.remove(nr_faa + '.cdhit')
+        clstr = nr_faa + '.cdhit.clstr'
 
-    header_to_allele = rename_genes_and_alleles(
-        clstr, nr_faa, nr_faa, _p(output_dir, name, '_allele_names.tsv'), name=name,
-        cluster_type='cds', shared_headers_file=shared, fastasort_path=fastasort_path)
-    df_alleles, df_genes = build_genetic_feature_tables(
-        clstr, genome_faa_paths, name, cluster_type='cds',
-        output_format=output_format, header_to_allele=header_to_allele)
+        header_to_allele = rename_genes_and_alleles(
+            clstr, nr_faa, nr_faa, _p(output_dir, name, '_allele_names.tsv'), name=name,
+            cluster_type='cds', shared_headers_file=shared, fastasort_path=fastasort_path)
+        df_alleles, df_genes = build_genetic_feature_tables(
+            clstr, genome_faa_paths, name, cluster_type='cds',
+            output_format=output_format, header_to_allele=header_to_allele)
 
     allele_npz = _p(output_dir, name, '_strain_by_allele') + '.npz'
     gene_npz = _p(output_dir, name, '_strain_by_gene') + '.npz'
@@ -463,18 +569,23 @@ def build_noncoding_pangenome(genome_data, output_dir, name='Test', flanking=(0,
     nr_fna = _p(output_dir, name, '_noncoding_nr.fna')
     shared = _p(output_dir, name, '_noncoding_redundant_headers.tsv')
     missing = _p(output_dir, name, '_noncoding_missing_headers.txt')
-    consolidate_seqs(nc_paths, nr_fna, shared, missing)
+    fast = _native_pipeline(nc_paths, nr_fna, shared, missing, _p(output_dir, name, '_noncoding_allele_names.tsv'),
+                            name, 'noncoding', cdhit_args, fastasort_path) if output_format == 'lsdf' else None
+    if fast is not None:
+        df_alleles, df_genes = fast
+    else:
+        consolidate_seqs(nc_paths, nr_fna, shared, missing)
 
-    cluster_with_cdhit(nr_fna, nr_fna + '.cdhit', cdhit_args)
-    os.remove(nr_fna + '.cdhit')
-    clstr = nr_fna + '.cdhit.clstr'
+        cluster_with_cdhit(nr_fna, nr_fna + '.cdhit', cdhit_args)
+        os.remove(nr_fna + '.cdhit')
+        clstr = nr_fna + '.cdhit.clstr'
 
-    header_to_allele = rename_genes_and_alleles(
-        clstr, nr_fna, nr_fna, _p(output_dir, name, '_noncoding_allele_names.tsv'), name=name,
-        cluster_type='noncoding', shared_headers_file=shared, fastasort_path=fastasort_path)
-    df_alleles, df_genes = build_genetic_feature_tables(
-        clstr, nc_paths, name, cluster_type='noncoding',
-        output_format=output_format, header_to_allele=header_to_allele)
+        header_to_allele = rename_genes_and_alleles(
+            clstr, nr_fna, nr_fna, _p(output_dir, name, '_noncoding_allele_names.tsv'), name=name,
+            cluster_type='noncoding', shared_headers_file=shared, fastasort_path=fastasort_path)
+        df_alleles, df_genes = build_genetic_feature_tables(
+            clstr, nc_paths, name, cluster_type='noncoding',
+            output_format=output_format, header_to_allele=header_to_allele)
     # plain lists on purpose; the maps are not refreshed (reference :292-293, App. B.5)
     strip = '_noncoding' + fna_output_footer
     df_alleles.columns = [x.replace(strip, '') for x in df_alleles.columns]
