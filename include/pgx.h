@@ -118,10 +118,28 @@ int pgx_pan_core(pgx_ctx *ctx, const uint64_t *bits, uint32_t n_genes, uint32_t 
 int pgx_pan_core_coo(pgx_ctx *ctx, const int32_t *row_of_record, const int32_t *genome_of_record,
                      uint64_t n_records, uint32_t n_genes, uint32_t n_genomes, const int32_t *perms,
                      uint32_t n_iter, int32_t *out_pan, int32_t *out_core, uint64_t *out_duplicates);
+/* Row occupancy: out_counts[r] = number of genomes that hold row r (gene or allele) = the popcount of
+ * the row across the bitmap. What core_genome.py:127-155 (count_gene_occurence) and
+ * allele_identification.py:129-157 (count_allele_occurence) obtain from the .npz triples with a pandas
+ * groupby; equal to their counts for a table without duplicate coordinates (duplicates reported). */
+int pgx_row_counts(pgx_ctx *ctx, const int32_t *row_of_record, const int32_t *genome_of_record,
+                   uint64_t n_records, uint32_t n_rows, uint32_t n_genomes, int32_t *out_counts,
+                   uint64_t *out_duplicates);
+int pgx_row_counts_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_rows, uint32_t n_genomes,
+                       int32_t *d_counts, void *stream);
 size_t pgx_pan_core_workspace_bytes(uint32_t n_genes, uint32_t n_genomes, uint32_t n_iter);
 int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uint32_t n_genomes,
                      const int32_t *d_perms, uint32_t n_iter, int32_t *d_out_pan,
                      int32_t *d_out_core, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Heaps-law fits of the pan curves (pangenome_analysis.py:24-48, fit_heaps_by_iteration): per
+ * iteration i the least-squares (alpha, kappa) of  pan[i][j-1] = kappa * j^alpha,  j = 1..n_genomes, from
+ * the reference's start point (0.5, min of the row). Floating point: equal to scipy's curve_fit to a
+ * tolerance (tests: rtol 1e-6). The device variant reads pgx_pan_core_dev's int32 output in place. */
+int pgx_heaps_fit(pgx_ctx *ctx, const double *pan, uint32_t n_iter, uint32_t n_genomes, double *out_alpha,
+                  double *out_kappa);
+int pgx_heaps_fit_dev(pgx_ctx *ctx, const int32_t *d_pan, uint32_t n_iter, uint32_t n_genomes,
+                      double *d_alpha, double *d_kappa, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * K1/K2: greedy incremental clustering with cd-hit's rules.

@@ -92,6 +92,10 @@ SIGNATURES = {
     'pgx_pan_core_coo': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, _P,
                                    C.POINTER(C.c_uint64)]),
     'pgx_pan_core': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, _P]),
+    'pgx_row_counts': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint64)]),
+    'pgx_row_counts_dev': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P]),
+    'pgx_heaps_fit': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P]),
+    'pgx_heaps_fit_dev': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     'pgx_pan_core_workspace_bytes': (C.c_size_t, [C.c_uint32, C.c_uint32, C.c_uint32]),
     'pgx_pan_core_dev': (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, C.c_uint32, _P, _P, _P,
                                    C.c_size_t, _P]),
@@ -233,6 +237,28 @@ class Context(object):
         check(lib().pgx_presence_bitmap(self._h, _ptr(rows), _ptr(genomes), rows.size,
                                         int(n_rows), int(n_genomes), _ptr(bits), C.byref(dup)))
         return (bits, int(dup.value)) if return_duplicates else bits
+
+    def heaps_fit(self, pan):
+        """(alpha, kappa) float64 per row of the pan table [n_iter, n_genomes]."""
+        pan = np.ascontiguousarray(pan, dtype=np.float64)
+        if pan.ndim != 2:
+            raise ValueError('pan must be [n_iter, n_genomes]')
+        alpha = np.empty(pan.shape[0], dtype=np.float64)
+        kappa = np.empty(pan.shape[0], dtype=np.float64)
+        check(lib().pgx_heaps_fit(self._h, _ptr(pan), pan.shape[0], pan.shape[1], _ptr(alpha), _ptr(kappa)))
+        return alpha, kappa
+
+    def row_counts(self, rows, genomes, n_rows, n_genomes):
+        """(counts int32[n_rows], duplicates): genomes per row, from the device bitmap."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        genomes = np.ascontiguousarray(genomes, dtype=np.int32)
+        if rows.shape != genomes.shape or rows.ndim != 1:
+            raise ValueError('rows and genomes must be 1-D arrays of equal length')
+        counts = np.empty(int(n_rows), dtype=np.int32)
+        dup = C.c_uint64(0)
+        check(lib().pgx_row_counts(self._h, _ptr(rows), _ptr(genomes), rows.size, int(n_rows), int(n_genomes),
+                                   _ptr(counts), C.byref(dup)))
+        return counts, int(dup.value)
 
     def pan_core_coo(self, rows, genomes, n_genes, n_genomes, perms):
         """(pan, core, duplicates): bitmap built and consumed on the device in one call."""

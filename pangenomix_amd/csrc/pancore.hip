@@ -189,9 +189,24 @@ __global__ __launch_bounds__(256) void presence_bitmap_kernel(const int32_t *__r
     }
 }
 
+// Row occupancy of the bitmap: in how many genomes is gene (or allele) r present? One thread per row; the
+// 64 rows of a wave share their word, so every genome costs the wave one load. What the reference's
+// downstream consumers compute from the .npz triples with a pandas groupby (core_genome.py:127-155,
+// allele_identification.py:129-157) and then threshold (core_genome.py:107-124).
+__global__ __launch_bounds__(256) void row_counts_kernel(const unsigned long long *__restrict__ bits, uint32_t stride,
+                                                        uint32_t n_genomes, uint32_t n_rows,
+                                                        int32_t *__restrict__ counts) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t w = r >> 6, b = r & 63u;
+    int32_t c = 0;
+    for (uint32_t s = 0; s < n_genomes; ++s) c += (int32_t)((bits[(size_t)s * stride + w] >> b) & 1ull);
+    counts[r] = c;
+}
+
 // K3 device buffers of the host-pointer entry points live in the context's grow-only workspace
 // (slots after the clustering's), so repeated calls neither allocate nor free.
-enum { PC_SLOT_ROWS = 80, PC_SLOT_GENOMES, PC_SLOT_BITS, PC_SLOT_PERMS, PC_SLOT_PAN, PC_SLOT_CORE, PC_SLOT_WS, PC_SLOT_CNT };
+enum { PC_SLOT_ROWS = 80, PC_SLOT_GENOMES, PC_SLOT_BITS, PC_SLOT_PERMS, PC_SLOT_PAN, PC_SLOT_CORE, PC_SLOT_WS, PC_SLOT_CNT, PC_SLOT_COUNTS };
 struct PcBuf : DevBuf {
     PcBuf(pgx_ctx *c, int s) { ctx = c; slot = s; }
 };
@@ -353,6 +368,42 @@ int pgx_pan_core_coo(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, 
         if (rc != PGX_OK) return rc;
     }
     uint64_t cnt[2] = {0, 0};
+    PGX_HIP(hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipStreamSynchronize(ctx->stream));
+    PGX_REQUIRE(cnt[1] == 0, "record with row or genome index out of range");
+    if (out_duplicates) *out_duplicates = cnt[0];
+    return PGX_OK;
+}
+
+int pgx_row_counts_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_rows, uint32_t n_genomes, int32_t *d_counts,
+                       void *stream_) {
+    PGX_REQUIRE(ctx, "NULL context");
+    if (n_rows == 0) return PGX_OK;
+    PGX_REQUIRE(d_bits && d_counts, "NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    {
+        ProfScope prof(ctx, "row_counts_kernel", stream);
+        row_counts_kernel<<<(n_rows + 255) / 256, 256, 0, stream>>>((const unsigned long long *)d_bits,
+                                                                    pgx_bitmap_stride_words(n_rows), n_genomes, n_rows, d_counts);
+    }
+    PGX_HIP(hipGetLastError());
+    return PGX_OK;
+}
+
+int pgx_row_counts(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, uint64_t n_records, uint32_t n_rows,
+                   uint32_t n_genomes, int32_t *out_counts, uint64_t *out_duplicates) {
+    PGX_REQUIRE(ctx, "NULL context");
+    PGX_REQUIRE(n_records == 0 || (rows && genomes), "NULL record arrays");
+    PGX_REQUIRE(n_rows == 0 || out_counts, "NULL argument");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    PcBuf d_bits(ctx, PC_SLOT_BITS), d_cnt(ctx, PC_SLOT_CNT), d_counts(ctx, PC_SLOT_COUNTS);
+    int rc = upload_and_build_bitmap(ctx, rows, genomes, n_records, n_rows, n_genomes, d_bits, d_cnt);
+    if (rc != PGX_OK) return rc;
+    PGX_HIP(d_counts.alloc((size_t)n_rows * 4));
+    rc = pgx_row_counts_dev(ctx, d_bits.as<uint64_t>(), n_rows, n_genomes, d_counts.as<int32_t>(), ctx->stream);
+    if (rc != PGX_OK) return rc;
+    uint64_t cnt[2] = {0, 0};
+    if (n_rows) PGX_HIP(hipMemcpyAsync(out_counts, d_counts.p, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     PGX_HIP(hipStreamSynchronize(ctx->stream));
     PGX_REQUIRE(cnt[1] == 0, "record with row or genome index out of range");
