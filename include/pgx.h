@@ -268,8 +268,8 @@ const uint8_t *pgx_fasta_digests(const pgx_fasta_set *fs);           /* [n_group
 const char *pgx_fasta_header_blob(const pgx_fasta_set *fs);          /* the records' headers, concatenated: */
 const uint64_t *pgx_fasta_header_offsets(const pgx_fasta_set *fs);   /* [n_records + 1] */
 /* consolidate_seqs()'s files: non-redundant FASTA, groups with several headers, headers without sequence */
-int pgx_fasta_write_consolidated(const pgx_fasta_set *fs, const char *nr_path, const char *shared_path,
-                                 const char *missing_path /* may be NULL */);
+int pgx_fasta_write_consolidated(const pgx_fasta_set *fs, const char *nr_path /* may be NULL */,
+                                 const char *shared_path, const char *missing_path /* may be NULL */);
 /* after pgx_cluster_greedy on (residues, offsets): cd-hit's .clstr, the allele name table
  * (<prefix><cluster><variant><member> TAB header TAB synonyms) and the non-redundant FASTA with the
  * allele names as headers (unclustered records dropped). NULL paths are skipped. */
@@ -277,6 +277,11 @@ int pgx_fasta_write_clustered(const pgx_fasta_set *fs, const int32_t *cluster, c
                               const float *identity, const uint8_t *strand /* may be NULL */, int nucleotide,
                               const char *prefix, const char *variant, const char *clstr_path,
                               const char *names_path, const char *nr_out_path);
+
+/* feature names (pangenome.py:1944-1969) as fixed-width zero-padded ASCII records (numpy 'S<width>'):
+ * <prefix><cluster>[<variant><member>]; variant NULL = gene names */
+int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
+                      uint64_t n, uint32_t width, char *out);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ SIGNATURES = {
     'pgx_fasta_header_blob': (_P, [_P]),
     'pgx_fasta_header_offsets': (_P, [_P]),
     'pgx_fasta_write_consolidated': (C.c_int, [_P, _S, _S, _S]),
+    'pgx_format_labels': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_fasta_write_clustered': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _S, _S, _S, _S, _S]),
     'pgx_version': (C.c_int, []),
     'pgx_last_error': (C.c_char_p, []),
@@ -374,7 +375,7 @@ class FastaSet(object):
         return [blob[off[i]:off[i + 1]].decode('ascii') for i in idx]
 
     def write_consolidated(self, nr_path, shared_path, missing_path=None):
-        check(lib().pgx_fasta_write_consolidated(self._h, os.fsencode(nr_path), os.fsencode(shared_path),
+        check(lib().pgx_fasta_write_consolidated(self._h, os.fsencode(nr_path) if nr_path else None, os.fsencode(shared_path),
                                                  os.fsencode(missing_path) if missing_path else None))
 
     def write_clustered(self, cluster, member, identity, strand, nucleotide, prefix, variant,
@@ -389,6 +390,19 @@ class FastaSet(object):
         check(lib().pgx_fasta_write_clustered(self._h, _ptr(cluster), _ptr(member), _ptr(identity), _ptr(strand),
                                               1 if nucleotide else 0, prefix.encode(), variant.encode(),
                                               enc(clstr_path), enc(names_path), enc(nr_out_path)))
+
+
+def format_labels(prefix, cluster, member=None, variant=None):
+    """numpy unicode array of feature names <prefix><cluster>[<variant><member>] (reference
+    pangenome.py:1944-1969), formatted by the library."""
+    cluster = np.ascontiguousarray(cluster, dtype=np.int32)
+    if variant is not None:
+        member = np.ascontiguousarray(member, dtype=np.int32)
+    width = len(prefix.encode()) + 11 + (len(variant) + 11 if variant is not None else 0)
+    out = np.zeros(cluster.size, dtype='S%d' % width)
+    check(lib().pgx_format_labels(prefix.encode(), variant.encode() if variant is not None else None, _ptr(cluster),
+                                  _ptr(member) if variant is not None else None, cluster.size, width, _ptr(out)))
+    return out.astype('U')
 
 
 _default_ctx = None

@@ -444,8 +444,8 @@ static void put_header(Out &o, const pgx_fasta_set *S, uint64_t r) {
 // tab-separated), the headers without sequence.
 int pgx_fasta_write_consolidated(const pgx_fasta_set *S, const char *nr_path, const char *shared_path,
                                  const char *missing_path) {
-    if (!S || !S->simple || !nr_path || !shared_path) { pgx_set_error("pgx_fasta_write_consolidated: invalid argument"); return PGX_ERR_INVALID; }
-    {
+    if (!S || !S->simple || !shared_path) { pgx_set_error("pgx_fasta_write_consolidated: invalid argument"); return PGX_ERR_INVALID; }
+    if (nr_path) {
         Out o(nr_path);
         if (!o.ok()) { pgx_set_error("cannot write %s", nr_path); return PGX_ERR_INVALID; }
         for (uint64_t k = 0; k < S->n_groups; ++k) {
@@ -539,6 +539,25 @@ int pgx_fasta_write_clustered(const pgx_fasta_set *S, const int32_t *cluster, co
             put_body(o, S, S->rec(S->rep_of_group[k]));
         }
         if (!o.close()) { pgx_set_error("write to %s failed", nr_out_path); return PGX_ERR_INVALID; }
+    }
+    return PGX_OK;
+}
+
+// Feature names as fixed-width, zero-padded ASCII records (numpy dtype 'S<width>'):
+// <prefix><cluster[i]>            (variant == NULL: gene names)
+// <prefix><cluster[i]><variant><member[i]>   (allele names), reference pangenome.py:1944-1969.
+int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
+                      uint64_t n, uint32_t width, char *out) {
+    if (!prefix || !cluster || (variant && !member) || (n && !out)) { pgx_set_error("pgx_format_labels: NULL argument"); return PGX_ERR_INVALID; }
+    const size_t pl = strlen(prefix);
+    char num[64];
+    for (uint64_t i = 0; i < n; ++i) {
+        const int k = variant ? snprintf(num, sizeof num, "%d%s%d", cluster[i], variant, member[i]) : snprintf(num, sizeof num, "%d", cluster[i]);
+        if (pl + (size_t)k > width) { pgx_set_error("pgx_format_labels: width %u too small", width); return PGX_ERR_INVALID; }
+        char *o = out + i * width;
+        memcpy(o, prefix, pl);
+        memcpy(o + pl, num, (size_t)k);
+        memset(o + pl + k, 0, width - pl - (size_t)k);
     }
     return PGX_OK;
 }

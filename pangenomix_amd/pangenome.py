@@ -430,7 +430,8 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         if not fs.simple:
             print('Note: taking the step-by-step path (%s)' % fs.why)
             return None
-        fs.write_consolidated(nr_fasta, shared, missing)                       # H1 (:336-405)
+        # H1 (:336-405); the nr FASTA itself is written once, below, with the allele names (:524-544 rewrites it)
+        fs.write_consolidated(None, shared, missing)
         print('Headers without sequences:', fs.n_missing)
         nucleotide = nr_fasta[-4:].lower() == '.fna'                           # K1/K2 (:425-450)
         params = cluster.params_from_cdhit_args(cdhit_args, 'nt' if nucleotide else 'aa')
@@ -460,8 +461,8 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         new_gene = np.ones(c_sorted.size, dtype=bool)
         new_gene[1:] = c_sorted[1:] != c_sorted[:-1]
         gene_of_allele = np.cumsum(new_gene) - 1
-        allele_order = [prefix + '%dA%d' % cm for cm in zip(c_sorted.tolist(), mem[allele_groups].tolist())]
-        gene_order = [prefix + str(c) for c in c_sorted[new_gene].tolist()]
+        allele_order = _native.format_labels(prefix, c_sorted, mem[allele_groups], VARIANT_TYPES['allele'])
+        gene_order = _native.format_labels(prefix, c_sorted[new_gene])
         print('Genomes:', len(genome_order))
         print('Clusters:', len(gene_order))
         print('Alleles:', len(allele_order))

@@ -1,6 +1,6 @@
 """Critical-path view of a rocprofv3 --kernel-trace CSV of one clustering run: per kernel, the
 time it occupies on the main stream, and the idle gaps of that stream (host round trips,
-launch latency). Usage: python tools/timeline.py <kernel_trace.csv> [main_queue_id|auto [sweep_to_dump]]"""
+launch latency). Usage: python tools/timeline.py <kernel_trace.csv> [main_queue_id|auto [window_to_dump]]"""
 import re
 import sys
 
@@ -8,12 +8,11 @@ import pandas as pd
 
 
 def short(name):
-    m = re.search(r'(\w+_kernel|DeviceScan\w*|\w+Kernel)\b', name)
-    base = m.group(1) if m else name[:40]
-    m2 = re.search(r'count_kernel<(\d)', name)
-    if m2:
-        base = 'count<%s>' % ('table', 'new', 'block')[int(m2.group(1))]
-    return base
+    m = re.search(r'filter_kernel<(true|false), (true|false)>', name)
+    if m:
+        return 'filter<%s>' % ('new' if m.group(2) == 'true' else 'all')
+    m = re.search(r'(\w+_kernel|\w+Kernel)\b', name)
+    return m.group(1) if m else name[:40]
 
 
 def main():
@@ -46,30 +45,9 @@ def main():
     gg['sum'] /= 1e3
     print('idle before (sum ms, n, mean us):  total %.1f ms' % (gap.sum() / 1e3))
     print(gg.head(12).to_string(float_format=lambda x: '%.1f' % x))
-    # does a sweep have to wait for its head (index + table pass, side stream, started one sweep earlier)?
-    init = m[m.k == 'sweep_init_kernel']
-    heads = s[s.k == 'count<table>']
-    if len(init) > 2 and len(heads) > 2:
-        import numpy as np
-        t_init = init.End_Timestamp.values
-        nxt = m[m.k == 'count<table>'].Start_Timestamp.values            # catch-up pass = first kernel after the wait
-        head_end = heads.End_Timestamp.values
-        late, gaps = [], []
-        for i, t in enumerate(t_init):
-            j = np.searchsorted(nxt, t)
-            if j >= len(nxt):
-                break
-            gaps.append((nxt[j] - t) / 1e3)
-            h = np.searchsorted(head_end, nxt[j], side='right') - 1     # last head that ended before the catch-up started
-            late.append((head_end[h] - t) / 1e3 if h >= 0 else 0.0)
-        gaps, late = np.array(gaps), np.array(late)
-        print('sweep start: idle between sweep_init and the catch-up pass: mean %.0f us, median %.0f, p90 %.0f; '
-              'sweeps whose head finished after sweep_init: %d of %d (mean lateness of those %.0f us)'
-              % (gaps.mean(), np.median(gaps), np.percentile(gaps, 90), (late > 0).sum(), len(late),
-                 late[late > 0].mean() if (late > 0).any() else 0.0))
-    if len(sys.argv) > 3:   # dump the launches of sweeps [N, N + 1): from the N-th sweep_init_kernel on
+    if len(sys.argv) > 3:   # dump the launches of windows [N, N + 1): from the N-th window_init_kernel on
         n_sw = int(sys.argv[3])
-        starts = d[d.k == 'sweep_init_kernel'].Start_Timestamp.values
+        starts = d[d.k == 'window_init_kernel'].Start_Timestamp.values
         a, b = starts[n_sw], starts[n_sw + 2]
         w = d[(d.Start_Timestamp >= a - 200000) & (d.Start_Timestamp < b)]
         for _, r in w.iterrows():
