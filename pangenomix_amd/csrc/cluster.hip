@@ -436,9 +436,16 @@ __device__ __noinline__ uint32_t word_mult_of(const uint32_t *__restrict__ wcode
     return wmult[o + lo];
 }
 
+__device__ __forceinline__ void wave_lds_sync() {   // LDS writes of this wave's lanes visible to all its lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 struct FilterWave {   // a wave's private LDS
     uint32_t *bucket, *hrep, *hcnt, *hminc;
     uint4 *lq;
+    uint32_t *pref;
 };
 
 // exact table: slot of representative r (inserted if absent), or kFH when the table is full
@@ -464,7 +471,6 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
                                             uint64_t o, uint32_t nw, uint32_t q, uint32_t thr, bool count_only,
                                             uint32_t class_k, uint32_t class_j, uint32_t &visits, bool &hot,
                                             bool &full) {
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     auto entry_visit = [&](uint32_t entry, uint32_t code, uint32_t mq) {
         const uint32_t r = entry & ~kMultiBit;
         if (r >= q) return;                      // only representatives created before the query
@@ -510,31 +516,28 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             e = j == 9 ? ld.z : e; e = j == 10 ? ld.w : e;
             entry_visit(e, code, mq);
         }
-        // lists longer than the line: queued, then walked by the whole wave with coalesced loads
+        // lists longer than the line: their pool parts are flattened into one run of entries that the whole
+        // wave walks, one entry per lane and step, whatever the lists' lengths (a list of one new entry
+        // and a list of thousands cost what their entries cost)
         const bool longl = hi > kInline && hi > lo;
-        const unsigned long long lm = __ballot(longl);
-        if (lm) {
-            if (longl) {
-                const uint32_t from = lo > kInline ? lo : kInline;
-                W.lq[__popcll(lm & lt_mask)] = make_uint4(la.y + 1u + (from - kInline), hi - from, code, mq);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t nl = (uint32_t)__popcll(lm);
-            for (uint32_t i = 0; i < nl; ++i) {
-                const uint4 it = W.lq[i];
-                for (uint32_t e = lane; e < it.y; e += 64) entry_visit(A.pool[it.x + e], it.z, it.w);
+        if (__ballot(longl)) {
+            const uint32_t from = lo > kInline ? lo : kInline;
+            const uint32_t cnt_l = longl ? hi - from : 0u;
+            uint32_t incl = cnt_l;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if ((int)lane >= d) incl += y; }
+            const uint32_t total = __shfl(incl, 63);
+            W.lq[lane] = make_uint4(la.y + 1u + (from - kInline), incl - cnt_l, code, mq);
+            W.pref[lane] = incl;
+            wave_lds_sync();
+            for (uint32_t t = lane; t < total; t += 64) {
+                uint32_t a = 0, b = 63;                    // the list that holds entry t: first prefix > t
+                while (a < b) { const uint32_t mid = (a + b) >> 1; if (W.pref[mid] > t) b = mid; else a = mid + 1; }
+                const uint4 it = W.lq[a];
+                entry_visit(A.pool[it.x + (t - it.y)], it.z, it.w);
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
-}
-
-__device__ __forceinline__ void wave_lds_sync() {   // LDS writes of this wave's lanes visible to all its lanes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 template <bool NT, bool NEWONLY>
@@ -542,10 +545,11 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][kFB];
     __shared__ uint32_t s_hrep[4][kFH], s_hcnt[4][kFH], s_hminc[4][kFH];
     __shared__ uint4 s_lq[4][64];
+    __shared__ uint32_t s_pref[4][64];
     __shared__ uint2 s_work[4][kFWork];
     if (NEWONLY && *A.d_round_lo >= *A.d_round_hi) return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const FilterWave W{s_bucket[wave], s_hrep[wave], s_hcnt[wave], s_hminc[wave], s_lq[wave]};
+    const FilterWave W{s_bucket[wave], s_hrep[wave], s_hcnt[wave], s_hminc[wave], s_lq[wave], s_pref[wave]};
     uint2 *work = s_work[wave];
     for (uint32_t i = lane; i < kFB; i += 64) W.bucket[i] = 0u;
     for (uint32_t i = lane; i < kFH; i += 64) { W.hrep[i] = kEmpty; W.hcnt[i] = 0u; W.hminc[i] = kSentinel; }
@@ -794,6 +798,13 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
             list[atomicAdd(n_list, 1u)] = k;
         }
     }
+}
+
+// (hipMemsetAsync between kernels left the stream idle for ~130 us each time -- 55 ms per run in the
+// first timeline of this design -- so the per-round clears are launches of our own)
+__global__ __launch_bounds__(256) void zero_kernel(uint4 *__restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // small bookkeeping kernels -----------------------------------------------------------------
@@ -1761,10 +1772,10 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_lines.alloc((size_t)n_codes * sizeof(IndexLine)));
     PGX_HIP(hipMemsetAsync(d_lines.p, 0, (size_t)n_codes * sizeof(IndexLine), st));
     PGX_HIP(d_idx.alloc(16));
-    PGX_HIP(d_newbits.alloc(((size_t)n_codes / 32 + 2) * 4));
+    PGX_HIP(d_newbits.alloc(((size_t)n_codes / 32 + 2) * 4 + 16));
     PGX_HIP(d_touched.alloc((max_window_words + 16) * 4));
     PGX_HIP(d_first.alloc((size_t)kMaxChunks * n_codes * 4));   // per-chunk first-open tags
-    PGX_HIP(d_chunkbits.alloc((size_t)n_codes * 4));
+    PGX_HIP(d_chunkbits.alloc((size_t)n_codes * 4 + 16));
     PGX_HIP(d_best_own.alloc((size_t)window_cap * 8));
     PGX_HIP(d_rcvis.alloc((size_t)window_cap * 8));
     PGX_HIP(d_blk_list.alloc((size_t)kBlockCap * 4));
@@ -2007,7 +2018,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // append list[*lo, *hi) to the index as round `epoch_idx` (the bit map of touched codes is the round's)
         auto index_append = [&](const uint32_t *list, const uint32_t *d_lo, const uint32_t *d_hi) -> int {
             ++epoch_idx;
-            PGX_HIP(hipMemsetAsync(d_newbits.p, 0, ((size_t)n_codes / 32 + 2) * 4, st));
+            zero_kernel<<<64, 256, 0, st>>>(d_newbits.as<uint4>(), ((size_t)n_codes / 32 + 2 + 3) / 4);
             ProfScope prof(ctx, "index_append", st);
             index_count_kernel<<<512, 256, 0, st>>>(DS, list, d_lo, d_hi, d_lines.as<IndexLine>(), d_touched.as<uint32_t>(),
                                                     dc + C_TOUCH, (uint32_t)max_window_words, dc + C_ERR);
@@ -2039,7 +2050,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // the device: the host learns the outcome with the first block's results.
         for (int round = 0; round < kDiscoveryRounds; ++round) {
             if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)kMaxChunks * n_codes * 4, st)); epoch_tag = 1; }
-            PGX_HIP(hipMemsetAsync(d_chunkbits.p, 0, (size_t)n_codes * 4, st));
+            zero_kernel<<<1024, 256, 0, st>>>(d_chunkbits.as<uint4>(), ((size_t)n_codes + 3) / 4);
             round_begin_kernel<<<1, 1, 0, st>>>(dc);
             list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN);
             LAUNCH_CHECK();

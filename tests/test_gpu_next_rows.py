@@ -27,7 +27,7 @@ def test_heaps_fit_reproduces_reference(path, gpu_ctx):
     fit = pa.fit_heaps_by_iteration(df, ctx=gpu_ctx)
     assert list(fit.columns) == [str(x) for x in want['columns']] == ['alpha', 'kappa']
     assert list(fit.index) == [str(x) for x in want['index']]
-    np.testing.assert_allclose(fit['alpha'].values, want['alpha'], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(fit["alpha"].values, want["alpha"], rtol=RTOL, atol=1e-7)   # (a flat curve: alpha = 0 up to the optimisers' stopping tolerance)
     np.testing.assert_allclose(fit['kappa'].values, want['kappa'], rtol=RTOL)
     np.testing.assert_array_equal(plot.calculate_mean(df).values[0], want['mean'])
 
