@@ -135,7 +135,7 @@ int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uin
 /* Heaps-law fits of the pan curves (pangenome_analysis.py:24-48, fit_heaps_by_iteration): per
  * iteration i the least-squares (alpha, kappa) of  pan[i][j-1] = kappa * j^alpha,  j = 1..n_genomes, from
  * the reference's start point (0.5, min of the row). Floating point: equal to scipy's curve_fit to a
- * tolerance (tests: rtol 1e-6). The device variant reads pgx_pan_core_dev's int32 output in place. */
+ * tolerance (tests: rtol 1e-5; scipy's default stopping rule leaves it ~3e-6 off the minimum). The device variant reads pgx_pan_core_dev's int32 output in place. */
 int pgx_heaps_fit(pgx_ctx *ctx, const double *pan, uint32_t n_iter, uint32_t n_genomes, double *out_alpha,
                   double *out_kappa);
 int pgx_heaps_fit_dev(pgx_ctx *ctx, const int32_t *d_pan, uint32_t n_iter, uint32_t n_genomes,

@@ -25,6 +25,9 @@
 //
 // Roofline: HBM/L2 streaming. Algorithmic bytes per iteration = S*ceil(G/64)*8 + 2*S*4 (+S*4
 // for the permutation), SURVEY §8d.
+#include <algorithm>
+#include <cstdlib>
+
 #include "pgx_internal.h"
 
 namespace {
@@ -145,6 +148,108 @@ __global__ __launch_bounds__(PC_WAVES * 64) void pan_core_sweep_kernel(
     }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// pan/core from LDS: the kernel used whenever all genome rows of a 256-byte slice fit a workgroup's LDS
+// ----------------------------------------------------------------------------------------
+// pan_core_sweep_kernel above re-reads the whole matrix from L2 in every iteration (7.5 GB per launch at
+// 150,000 x 400 x 1000: 0.31 of the aggregate L2 peak). Here a workgroup stages a SLICE -- the same 256
+// bytes (2048 genes) of all S rows: 100 KB at S = 400 -- in LDS once and runs 16 iterations over it, one
+// per half-wave: per step one broadcast read of the permutation entry and one conflict-free ds_read_b64 per
+// lane (a half-wave reads the row's 256 contiguous bytes), OR / AND / popcount, five DPP adds, and one LDS
+// add into the workgroup's (iteration, step) accumulators. The workgroup walks its group of <= 31 slices
+// (block b: slice group b % n_sg -- one XCD's L2 holds one group -- iterations 16 (b / n_sg) ...), so the matrix
+// crosses the L2 -> LDS path n_iter / 16 times instead of n_iter times and only n_sg partial tables are
+// written (8 x 1.6 MB at the benchmark's size; they were 24 x 1.6 MB).
+constexpr int LD_THREADS = 512;
+constexpr int LD_ITERS = LD_THREADS / 32;   // iterations per workgroup: one per half-wave
+constexpr uint32_t LD_SLICE = 256;          // bytes of a row per slice
+constexpr uint32_t LD_MAX_SLICES = 31;      // per group: 31 x 2048 genes stay below the 16-bit halves of an accumulator
+
+__device__ __forceinline__ uint32_t halfwave_sum_u32(uint32_t x) {   // lanes 16-31 / 48-63 end up with their half's sum
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);  // row_mirror
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);  // row_bcast15 -> rows 1,3
+    return x;
+}
+
+__global__ __launch_bounds__(LD_THREADS) void pan_core_lds_kernel(const char *__restrict__ bits, uint32_t stride_bytes,
+                                                                  const int32_t *__restrict__ perms, uint32_t n_iter,
+                                                                  uint32_t S, uint32_t S4, uint32_t n_slices, uint32_t n_sg,
+                                                                  uint32_t *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *rowbuf = lds;                                                              // S x 256 bytes
+    uint16_t *permbuf = reinterpret_cast<uint16_t *>(lds + (size_t)S * LD_SLICE);    // 16 x S4 (S rounded up to 4)
+    uint32_t *acc = reinterpret_cast<uint32_t *>(lds + (size_t)S * LD_SLICE + (size_t)LD_ITERS * S4 * 2);   // 16 x S4
+    const uint32_t tid = threadIdx.x, hw = tid >> 5, l32 = tid & 31u;
+    const uint32_t sg = blockIdx.x % n_sg, ig = blockIdx.x / n_sg;
+    const uint32_t s_lo = (uint32_t)((uint64_t)sg * n_slices / n_sg), s_hi = (uint32_t)((uint64_t)(sg + 1) * n_slices / n_sg);
+    const uint32_t iter = ig * LD_ITERS + hw;
+    const bool live = iter < n_iter;
+    for (uint32_t i = tid; i < LD_ITERS * S4; i += LD_THREADS) {
+        const uint32_t it = ig * LD_ITERS + i / S4, j = i % S4;
+        permbuf[i] = (it < n_iter && j < S) ? (uint16_t)perms[(size_t)it * S + j] : (uint16_t)0;
+        acc[i] = 0u;
+    }
+    const uint16_t *prow = permbuf + hw * S4;
+    uint32_t *arow = acc + hw * S4;
+    for (uint32_t slice = s_lo; slice < s_hi; ++slice) {
+        __syncthreads();   // the slice before has been consumed (and permbuf / acc are set up)
+        const uint32_t off = slice * LD_SLICE;
+        for (uint32_t c = tid; c < S * (LD_SLICE / 16); c += LD_THREADS) {   // 16 threads per row, coalesced 256-byte segments
+            const uint32_t r = c >> 4, ch = (c & 15u) * 16u;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (off + ch < stride_bytes) v = *reinterpret_cast<const uint4 *>(bits + (size_t)r * stride_bytes + off + ch);
+            *reinterpret_cast<uint4 *>(rowbuf + r * LD_SLICE + ch) = v;
+        }
+        __syncthreads();
+        if (!live) continue;
+        unsigned long long o = 0ull, a = ~0ull;
+        const char *lane_col = rowbuf + l32 * 8u;
+        for (uint32_t j = 0; j < S4; j += 4) {
+            // four steps at a time: their permutation entries in one read, their rows requested together
+            const uint2 p4 = *reinterpret_cast<const uint2 *>(prow + j);
+            const uint32_t r0 = p4.x & 0xFFFFu, r1 = p4.x >> 16, r2 = p4.y & 0xFFFFu, r3 = p4.y >> 16;
+            const unsigned long long v0 = *reinterpret_cast<const unsigned long long *>(lane_col + r0 * LD_SLICE);
+            const unsigned long long v1 = *reinterpret_cast<const unsigned long long *>(lane_col + r1 * LD_SLICE);
+            const unsigned long long v2 = *reinterpret_cast<const unsigned long long *>(lane_col + r2 * LD_SLICE);
+            const unsigned long long v3 = *reinterpret_cast<const unsigned long long *>(lane_col + r3 * LD_SLICE);
+            uint32_t c0, c1, c2, c3;
+            o |= v0; a &= v0; c0 = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
+            o |= v1; a &= v1; c1 = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
+            o |= v2; a &= v2; c2 = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
+            o |= v3; a &= v3; c3 = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
+            c0 = halfwave_sum_u32(c0); c1 = halfwave_sum_u32(c1); c2 = halfwave_sum_u32(c2); c3 = halfwave_sum_u32(c3);
+            if (l32 == 31u) {   // (steps >= S of the padded tail land in accumulators that are never stored)
+                uint4 *dst = reinterpret_cast<uint4 *>(arow + j);
+                uint4 t = *dst;
+                t.x += c0; t.y += c1; t.z += c2; t.w += c3;
+                *dst = t;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < LD_ITERS * S4; i += LD_THREADS) {
+        const uint32_t it = ig * LD_ITERS + i / S4, j = i % S4;
+        if (it < n_iter && j < S) partial[((size_t)sg * n_iter + it) * S + j] = acc[i];
+    }
+}
+
+struct LdsGeom { uint32_t S4, n_slices, n_sg; size_t lds_bytes; bool ok; };
+LdsGeom make_lds_geom(uint32_t n_genes, uint32_t n_genomes) {
+    LdsGeom g;
+    g.S4 = (n_genomes + 3u) & ~3u;
+    const uint32_t stride_bytes = pgx_bitmap_stride_words(n_genes) * 8u;
+    g.n_slices = (stride_bytes + LD_SLICE - 1) / LD_SLICE;
+    g.n_sg = std::max<uint32_t>(PC_STRIPES, ((g.n_slices + LD_MAX_SLICES - 1) / LD_MAX_SLICES + PC_STRIPES - 1) / PC_STRIPES * PC_STRIPES);
+    if (g.n_sg > g.n_slices) g.n_sg = g.n_slices;
+    g.lds_bytes = (size_t)n_genomes * LD_SLICE + (size_t)LD_ITERS * g.S4 * 6;
+    g.ok = g.lds_bytes <= 160 * 1024 && n_genomes <= 65535 && n_genomes >= 1;
+    return g;
+}
+
 __global__ __launch_bounds__(256) void pan_core_reduce_kernel(const uint32_t *__restrict__ partial,
                                                              uint32_t n_partials, size_t n_out,
                                                              int32_t *__restrict__ out_pan,
@@ -223,7 +328,9 @@ uint32_t pgx_bitmap_stride_words(uint32_t n_genes) {
 
 size_t pgx_pan_core_workspace_bytes(uint32_t n_genes, uint32_t n_genomes, uint32_t n_iter) {
     const PanCoreGeom g = make_geom(n_genes);
-    return (size_t)g.partials * n_iter * n_genomes * sizeof(uint32_t);
+    const LdsGeom l = make_lds_geom(n_genes, n_genomes);
+    const uint32_t partials = std::max<uint32_t>(g.partials, l.ok ? l.n_sg : 0u);
+    return (size_t)partials * n_iter * n_genomes * sizeof(uint32_t);
 }
 
 int pgx_presence_bitmap_dev(pgx_ctx *ctx, const int32_t *d_rows, const int32_t *d_genomes,
@@ -295,10 +402,27 @@ int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uin
     PGX_REQUIRE(((uintptr_t)d_bits & 15u) == 0, "bitmap must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     const PanCoreGeom g = make_geom(n_genes);
-    const uint64_t items = (uint64_t)n_iter * g.wps;  // per stripe
-    const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * PC_STRIPES;
-    PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
-    {
+    const LdsGeom l = make_lds_geom(n_genes, n_genomes);
+    uint32_t n_partials = g.partials;
+    static const bool force_l2 = std::getenv("PGX_PANCORE_L2") != nullptr;   // (the L2 kernel, for comparison runs)
+    if (l.ok && !force_l2) {
+        // all rows of a slice fit a workgroup's LDS: the matrix is staged there (see pan_core_lds_kernel)
+        static bool attr_set = false;
+        if (!attr_set) {
+            PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pan_core_lds_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const uint64_t blocks = (uint64_t)((n_iter + LD_ITERS - 1) / LD_ITERS) * l.n_sg;
+        PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
+        ProfScope prof(ctx, "pan_core_sweep_kernel", stream);
+        pan_core_lds_kernel<<<(uint32_t)blocks, LD_THREADS, l.lds_bytes, stream>>>(
+            (const char *)d_bits, g.stride * 8, d_perms, n_iter, n_genomes, l.S4, l.n_slices, l.n_sg, (uint32_t *)d_workspace);
+        n_partials = l.n_sg;
+    } else {
+        const uint64_t items = (uint64_t)n_iter * g.wps;  // per stripe
+        const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * PC_STRIPES;
+        PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
         ProfScope prof(ctx, "pan_core_sweep_kernel", stream);
         pan_core_sweep_kernel<<<(uint32_t)blocks, PC_WAVES * 64, 0, stream>>>(
             (const uint4 *)d_bits, g.stride * 8, d_perms, n_iter, n_genomes, g.Ls, g.wps, g.Lw,
@@ -310,7 +434,7 @@ int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uin
     {
         ProfScope prof(ctx, "pan_core_reduce_kernel", stream);
         pan_core_reduce_kernel<<<(uint32_t)(want < 2048 ? want : 2048), 256, 0, stream>>>(
-            (const uint32_t *)d_workspace, g.partials, n_out, d_out_pan, d_out_core);
+            (const uint32_t *)d_workspace, n_partials, n_out, d_out_pan, d_out_core);
     }
     PGX_HIP(hipGetLastError());
     return PGX_OK;
