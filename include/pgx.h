@@ -278,6 +278,11 @@ int pgx_fasta_write_clustered(const pgx_fasta_set *fs, const int32_t *cluster, c
                               const char *prefix, const char *variant, const char *clstr_path,
                               const char *names_path, const char *nr_out_path);
 
+/* n_iter permutations of 0..n-1 drawn exactly as `p = np.arange(n); np.random.shuffle(p)` draws them from
+ * numpy's legacy global generator (pangenome_analysis.py:84-85): MT19937 state key[624] / pos in, advanced
+ * state out (np.random.get_state() / set_state()). out_perms: [n_iter][n] int32. */
+int pgx_legacy_shuffles(uint32_t *key, int32_t *pos, uint32_t n, uint32_t n_iter, int32_t *out_perms);
+
 /* feature names (pangenome.py:1944-1969) as fixed-width zero-padded ASCII records (numpy 'S<width>'):
  * <prefix><cluster>[<variant><member>]; variant NULL = gene names */
 int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,

@@ -75,6 +75,7 @@ SIGNATURES = {
     'pgx_fasta_header_blob': (_P, [_P]),
     'pgx_fasta_header_offsets': (_P, [_P]),
     'pgx_fasta_write_consolidated': (C.c_int, [_P, _S, _S, _S]),
+    'pgx_legacy_shuffles': (C.c_int, [_P, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, _P]),
     'pgx_format_labels': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_fasta_write_clustered': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _S, _S, _S, _S, _S]),
     'pgx_version': (C.c_int, []),

@@ -543,6 +543,47 @@ int pgx_fasta_write_clustered(const pgx_fasta_set *S, const int32_t *cluster, co
     return PGX_OK;
 }
 
+// The permutations estimate_pan_core_size() consumes (pangenome_analysis.py:84-85): per iteration
+// `p = np.arange(S); np.random.shuffle(p)` on numpy's GLOBAL legacy generator. To keep a seeded run identical
+// to the reference's, the same stream has to be consumed in the same way: MT19937 (the legacy RandomState's
+// generator), numpy's random_interval (smallest bit mask >= i, 32-bit draws, rejection) and the
+// Fisher-Yates order of RandomState.shuffle (i = n-1 .. 1, swap x[i] <-> x[j]). The caller passes the
+// generator's state (np.random.get_state(): key[624], pos) and stores the advanced state back.
+static inline uint32_t mt_next(uint32_t *mt, int32_t *pos) {
+    if (*pos >= 624) {
+        auto twist = [&](int k, int k1, int km) {
+            const uint32_t y = (mt[k] & 0x80000000u) | (mt[k1] & 0x7fffffffu);
+            mt[k] = mt[km] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+        };
+        for (int k = 0; k < 227; ++k) twist(k, k + 1, k + 397);
+        for (int k = 227; k < 623; ++k) twist(k, k + 1, k - 227);
+        twist(623, 0, 396);
+        *pos = 0;
+    }
+    uint32_t y = mt[(*pos)++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+int pgx_legacy_shuffles(uint32_t *key, int32_t *pos, uint32_t n, uint32_t n_iter, int32_t *out_perms) {
+    if (!key || !pos || (n && n_iter && !out_perms) || *pos < 0 || *pos > 624) {
+        pgx_set_error("pgx_legacy_shuffles: invalid argument");
+        return PGX_ERR_INVALID;
+    }
+    for (uint32_t it = 0; it < n_iter; ++it) {
+        int32_t *x = out_perms + (size_t)it * n;
+        for (uint32_t i = 0; i < n; ++i) x[i] = (int32_t)i;
+        for (uint32_t i = n; i-- > 1;) {
+            uint32_t mask = i;
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+            uint32_t j;
+            while ((j = mt_next(key, pos) & mask) > i) {
+            }
+            const int32_t t = x[i]; x[i] = x[j]; x[j] = t;
+        }
+    }
+    return PGX_OK;
+}
+
 // Feature names as fixed-width, zero-padded ASCII records (numpy dtype 'S<width>'):
 // <prefix><cluster[i]>            (variant == NULL: gene names)
 // <prefix><cluster[i]><variant><member[i]>   (allele names), reference pangenome.py:1944-1969.

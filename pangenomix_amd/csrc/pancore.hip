@@ -208,26 +208,39 @@ __global__ __launch_bounds__(LD_THREADS) void pan_core_lds_kernel(const char *__
         if (!live) continue;
         unsigned long long o = 0ull, a = ~0ull;
         const char *lane_col = rowbuf + l32 * 8u;
+        // Four steps per trip, software-pipelined two deep: a step is a chain of two LDS reads (permutation
+        // entry -> row), and with one workgroup per CU there are only two waves per SIMD to hide them, so the
+        // entries of trip g+2 and the rows of trip g+1 are requested before trip g is folded.
+        auto rows_of = [&](uint2 p4, unsigned long long v[4]) {
+            v[0] = *reinterpret_cast<const unsigned long long *>(lane_col + (p4.x & 0xFFFFu) * LD_SLICE);
+            v[1] = *reinterpret_cast<const unsigned long long *>(lane_col + (p4.x >> 16) * LD_SLICE);
+            v[2] = *reinterpret_cast<const unsigned long long *>(lane_col + (p4.y & 0xFFFFu) * LD_SLICE);
+            v[3] = *reinterpret_cast<const unsigned long long *>(lane_col + (p4.y >> 16) * LD_SLICE);
+        };
+        unsigned long long vc[4], vn[4];
+        uint2 pn = *reinterpret_cast<const uint2 *>(prow + (S4 > 4 ? 4 : 0));
+        rows_of(*reinterpret_cast<const uint2 *>(prow), vc);
         for (uint32_t j = 0; j < S4; j += 4) {
-            // four steps at a time: their permutation entries in one read, their rows requested together
-            const uint2 p4 = *reinterpret_cast<const uint2 *>(prow + j);
-            const uint32_t r0 = p4.x & 0xFFFFu, r1 = p4.x >> 16, r2 = p4.y & 0xFFFFu, r3 = p4.y >> 16;
-            const unsigned long long v0 = *reinterpret_cast<const unsigned long long *>(lane_col + r0 * LD_SLICE);
-            const unsigned long long v1 = *reinterpret_cast<const unsigned long long *>(lane_col + r1 * LD_SLICE);
-            const unsigned long long v2 = *reinterpret_cast<const unsigned long long *>(lane_col + r2 * LD_SLICE);
-            const unsigned long long v3 = *reinterpret_cast<const unsigned long long *>(lane_col + r3 * LD_SLICE);
-            uint32_t c0, c1, c2, c3;
-            o |= v0; a &= v0; c0 = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
-            o |= v1; a &= v1; c1 = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
-            o |= v2; a &= v2; c2 = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
-            o |= v3; a &= v3; c3 = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
-            c0 = halfwave_sum_u32(c0); c1 = halfwave_sum_u32(c1); c2 = halfwave_sum_u32(c2); c3 = halfwave_sum_u32(c3);
+            rows_of(pn, vn);                                                     // rows of the next trip
+            const uint32_t j2 = j + 8 < S4 ? j + 8 : 0;                          // (past the end: any valid entry)
+            const uint2 pn2 = *reinterpret_cast<const uint2 *>(prow + j2);       // entries of the trip after next
+            uint32_t c[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                o |= vc[t]; a &= vc[t];
+                c[t] = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c[t] = halfwave_sum_u32(c[t]);
             if (l32 == 31u) {   // (steps >= S of the padded tail land in accumulators that are never stored)
                 uint4 *dst = reinterpret_cast<uint4 *>(arow + j);
-                uint4 t = *dst;
-                t.x += c0; t.y += c1; t.z += c2; t.w += c3;
-                *dst = t;
+                uint4 t4 = *dst;
+                t4.x += c[0]; t4.y += c[1]; t4.z += c[2]; t4.w += c[3];
+                *dst = t4;
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vc[t] = vn[t];
+            pn = pn2;
         }
     }
     __syncthreads();

@@ -421,11 +421,21 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
     treat specially (see pgx.h), duplicate genome names, an external fastasort, a multi-process group:
     the caller then runs the step-by-step functions. `cluster_fn(residues, offsets, params)` replaces the
     GPU clustering call in tests (the CPU oracle, or a reader of a given .clstr)."""
+    import sys
+    import time
     from . import _native, cluster
     genomes = [__get_genome_from_filename__(p) for p in genome_paths]
     if fastasort_path or cluster._group is not None or len(set(genomes)) != len(genomes):
         return None
+    t_mark = [time.perf_counter()]
+
+    def lap(what):   # PGX_TRACE: wall time of the pipeline's stages
+        if os.environ.get('PGX_TRACE'):
+            now = time.perf_counter()
+            print('[pgx] pipeline: %-28s %8.1f ms' % (what, (now - t_mark[0]) * 1e3), file=sys.stderr)
+            t_mark[0] = now
     fs = _native.FastaSet(genome_paths)
+    lap('ingest (parse, sha256, dedupe)')
     try:
         if not fs.simple:
             print('Note: taking the step-by-step path (%s)' % fs.why)
@@ -433,16 +443,19 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         # H1 (:336-405); the nr FASTA itself is written once, below, with the allele names (:524-544 rewrites it)
         fs.write_consolidated(None, shared, missing)
         print('Headers without sequences:', fs.n_missing)
+        lap('redundant / missing headers')
         nucleotide = nr_fasta[-4:].lower() == '.fna'                           # K1/K2 (:425-450)
         params = cluster.params_from_cdhit_args(cdhit_args, 'nt' if nucleotide else 'aa')
         print('Running: libpgx greedy clustering (%s rules) -i %s -o %s -c %g -n %d' % (
             'cd-hit-est' if nucleotide else 'cd-hit', nr_fasta, nr_fasta + '.cdhit', params.identity, params.word_len))
         cl, mem, iden, strand, n_clusters = (cluster_fn or cluster.cluster_sequences)(fs.residues, fs.offsets, params)[:5]
         print('%9d  finished  %9d  clusters' % (int((cl >= 0).sum()), n_clusters))
+        lap('clustering (H2D included)')
         prefix = name + '_' + CLUSTER_TYPES[cluster_type]                      # H2 (:453-560)
         fs.write_clustered(cl, mem, iden, strand, nucleotide, prefix, VARIANT_TYPES['allele'],
                            clstr_path=nr_fasta + '.cdhit.clstr', names_path=names_tsv, nr_out_path=nr_fasta + '.tmp')
         os.replace(nr_fasta + '.tmp', nr_fasta)
+        lap('.clstr, names, nr FASTA')
         unclustered = np.flatnonzero(cl < 0)
         if unclustered.size:
             for h in fs.headers(fs.rep_of_group[unclustered]):
@@ -486,8 +499,10 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         sp_alleles = _first_occurrence_coo(rec_allele, rec_genome, len(allele_order), len(genome_order))
         sp_genes = _first_occurrence_coo(gene_of_allele[rec_allele] if rec_allele.size else rec_allele,
                                          rec_genome, len(gene_order), len(genome_order))
-        return (sparse_utils.LightSparseDataFrame(allele_order, genome_order, sp_alleles),
-                sparse_utils.LightSparseDataFrame(gene_order, genome_order, sp_genes))
+        out = (sparse_utils.LightSparseDataFrame(allele_order, genome_order, sp_alleles),
+               sparse_utils.LightSparseDataFrame(gene_order, genome_order, sp_genes))
+        lap('tables')
+        return out
     finally:
         fs.close()
 
