@@ -226,6 +226,33 @@ struct Out {   // buffered file writer
     bool close() { if (!f) return true; flush(); const bool good = fclose(f) == 0; f = nullptr; return good; }
 };
 
+// A text file whose items can be formatted independently: the items are cut into chunks, the chunks are
+// formatted by all cores into strings, and the strings land in the file with positioned writes.
+template <typename F>
+bool parallel_write(const char *path, uint64_t n_items, int threads, F format /* (begin, end, std::string &out) */) {
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return false;
+    const size_t n_chunks = (size_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)threads * 4, (n_items + 4095) / 4096));
+    std::vector<std::string> parts(n_chunks);
+    parallel_for(n_chunks, threads, [&](size_t c) {
+        format(n_items * c / n_chunks, n_items * (c + 1) / n_chunks, parts[c]);
+    });
+    std::vector<uint64_t> at(n_chunks + 1, 0);
+    for (size_t c = 0; c < n_chunks; ++c) at[c + 1] = at[c] + parts[c].size();
+    std::atomic<bool> good{ftruncate(fd, (off_t)at[n_chunks]) == 0};
+    parallel_for(n_chunks, threads, [&](size_t c) {
+        const char *p = parts[c].data();
+        size_t left = parts[c].size();
+        uint64_t off = at[c];
+        while (left) {
+            const ssize_t w = pwrite(fd, p, left, (off_t)off);
+            if (w <= 0) { good = false; return; }
+            p += w; left -= (size_t)w; off += (uint64_t)w;
+        }
+    });
+    return close(fd) == 0 && good;
+}
+
 }  // namespace
 
 struct pgx_fasta_set {
@@ -246,6 +273,7 @@ struct pgx_fasta_set {
     std::vector<uint64_t> members;
     bool simple = true;
     std::string why;
+    int threads = 1;
     const Rec &rec(uint64_t r) const {
         const size_t f = file_of[r];
         return files[f].recs[r - first_rec[f]];
@@ -263,6 +291,7 @@ int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pg
     auto *S = new (std::nothrow) pgx_fasta_set();
     if (!S) { pgx_set_error("pgx_fasta_open: out of memory"); return PGX_ERR_NOMEM; }
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    S->threads = n_threads;
     S->files.resize(n_paths);
     for (uint32_t i = 0; i < n_paths; ++i) S->paths.emplace_back(paths[i]);
     const bool trace = std::getenv("PGX_TRACE") != nullptr;
@@ -430,10 +459,13 @@ const uint8_t *pgx_fasta_digests(const pgx_fasta_set *S) { return S && S->simple
 const char *pgx_fasta_header_blob(const pgx_fasta_set *S) { return S && S->simple ? S->hdr_blob.data() : nullptr; }
 const uint64_t *pgx_fasta_header_offsets(const pgx_fasta_set *S) { return S && S->simple ? S->hdr_off.data() : nullptr; }
 
-static void put_body(Out &o, const pgx_fasta_set *S, const Rec &rc) {
+static void add_body(std::string &o, const pgx_fasta_set *S, const Rec &rc) {
     const FileData &F = S->files[rc.file];
-    if (rc.body_alt >= 0) o.put(F.alt[(size_t)rc.body_alt]);
-    else o.put(F.map + rc.body_off, rc.body_len);
+    if (rc.body_alt >= 0) o += F.alt[(size_t)rc.body_alt];
+    else o.append(F.map + rc.body_off, rc.body_len);
+}
+static void add_header(std::string &o, const pgx_fasta_set *S, uint64_t r) {
+    o.append(&S->hdr_blob[S->hdr_off[r]], (size_t)(S->hdr_off[r + 1] - S->hdr_off[r]));
 }
 static void put_header(Out &o, const pgx_fasta_set *S, uint64_t r) {
     o.put(&S->hdr_blob[S->hdr_off[r]], (size_t)(S->hdr_off[r + 1] - S->hdr_off[r]));
@@ -446,14 +478,17 @@ int pgx_fasta_write_consolidated(const pgx_fasta_set *S, const char *nr_path, co
                                  const char *missing_path) {
     if (!S || !S->simple || !shared_path) { pgx_set_error("pgx_fasta_write_consolidated: invalid argument"); return PGX_ERR_INVALID; }
     if (nr_path) {
-        Out o(nr_path);
-        if (!o.ok()) { pgx_set_error("cannot write %s", nr_path); return PGX_ERR_INVALID; }
-        for (uint64_t k = 0; k < S->n_groups; ++k) {
-            const uint64_t r = S->rep_of_group[k];
-            o.put('>'); put_header(o, S, r); o.put('\n');
-            put_body(o, S, S->rec(r));
-        }
-        if (!o.close()) { pgx_set_error("write to %s failed", nr_path); return PGX_ERR_INVALID; }
+        const bool ok = parallel_write(nr_path, S->n_groups, S->threads, [&](uint64_t b, uint64_t e, std::string &o) {
+            uint64_t bytes = 0;
+            for (uint64_t k = b; k < e; ++k) bytes += S->rec(S->rep_of_group[k]).body_len + 64;
+            o.reserve(bytes);
+            for (uint64_t k = b; k < e; ++k) {
+                const uint64_t r = S->rep_of_group[k];
+                o.push_back('>'); add_header(o, S, r); o.push_back('\n');
+                add_body(o, S, S->rec(r));
+            }
+        });
+        if (!ok) { pgx_set_error("cannot write %s", nr_path); return PGX_ERR_INVALID; }
     }
     {
         Out o(shared_path);
@@ -498,47 +533,57 @@ int pgx_fasta_write_clustered(const pgx_fasta_set *S, const int32_t *cluster, co
     std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
         return cluster[a] != cluster[b] ? cluster[a] < cluster[b] : (member[a] != member[b] ? member[a] < member[b] : a < b);
     });
-    char num[96];
-    if (clstr_path) {
-        Out o(clstr_path);
-        if (!o.ok()) { pgx_set_error("cannot write %s", clstr_path); return PGX_ERR_INVALID; }
-        int32_t last = -1;
-        for (uint64_t k : order) {
-            if (cluster[k] != last) { last = cluster[k]; o.put(num, (size_t)snprintf(num, sizeof num, ">Cluster %d\n", last)); }
-            o.put(num, (size_t)snprintf(num, sizeof num, "%d\t%u%s, >", member[k], S->letters[k], nucleotide ? "nt" : "aa"));
-            put_header(o, S, S->rep_of_group[k]);
-            if (member[k] == 0) o.put("... *\n", 6);
-            else {
-                const float pct = identity[k] * 100.0f;
-                if (nucleotide) o.put(num, (size_t)snprintf(num, sizeof num, "... at %c/%.2f%%\n", strand && strand[k] ? '-' : '+', (double)pct));
-                else o.put(num, (size_t)snprintf(num, sizeof num, "... at %.2f%%\n", (double)pct));
-            }
-        }
-        if (!o.close()) { pgx_set_error("write to %s failed", clstr_path); return PGX_ERR_INVALID; }
-    }
-    auto put_name = [&](Out &o, uint64_t k) {
-        o.put(prefix, strlen(prefix));
-        o.put(num, (size_t)snprintf(num, sizeof num, "%d%s%d", cluster[k], variant, member[k]));
+    const int T = S->threads;
+    auto name_of = [&](std::string &o, uint64_t k) {
+        char num[64];
+        o.append(prefix);
+        o.append(num, (size_t)snprintf(num, sizeof num, "%d%s%d", cluster[k], variant, member[k]));
     };
+    // the three files are independent of one another and their items of each other: every file is formatted
+    // in chunks by all cores and written with positioned writes
+    if (clstr_path) {
+        const bool ok = parallel_write(clstr_path, order.size(), T, [&](uint64_t b, uint64_t e, std::string &o) {
+            char num[96];
+            o.reserve((e - b) * 64);
+            for (uint64_t i = b; i < e; ++i) {
+                const uint64_t k = order[i];
+                if (i == 0 || cluster[order[i - 1]] != cluster[k]) o.append(num, (size_t)snprintf(num, sizeof num, ">Cluster %d\n", cluster[k]));
+                o.append(num, (size_t)snprintf(num, sizeof num, "%d\t%u%s, >", member[k], S->letters[k], nucleotide ? "nt" : "aa"));
+                add_header(o, S, S->rep_of_group[k]);
+                if (member[k] == 0) o.append("... *\n", 6);
+                else {
+                    const float pct = identity[k] * 100.0f;
+                    if (nucleotide) o.append(num, (size_t)snprintf(num, sizeof num, "... at %c/%.2f%%\n", strand && strand[k] ? '-' : '+', (double)pct));
+                    else o.append(num, (size_t)snprintf(num, sizeof num, "... at %.2f%%\n", (double)pct));
+                }
+            }
+        });
+        if (!ok) { pgx_set_error("cannot write %s", clstr_path); return PGX_ERR_INVALID; }
+    }
     if (names_path) {
-        Out o(names_path);
-        if (!o.ok()) { pgx_set_error("cannot write %s", names_path); return PGX_ERR_INVALID; }
-        for (uint64_t k : order) {
-            put_name(o, k);
-            for (uint64_t i = S->members_off[k]; i < S->members_off[k + 1]; ++i) { o.put('\t'); put_header(o, S, S->members[i]); }
-            o.put('\n');
-        }
-        if (!o.close()) { pgx_set_error("write to %s failed", names_path); return PGX_ERR_INVALID; }
+        const bool ok = parallel_write(names_path, order.size(), T, [&](uint64_t b, uint64_t e, std::string &o) {
+            o.reserve((e - b) * 64);
+            for (uint64_t i = b; i < e; ++i) {
+                const uint64_t k = order[i];
+                name_of(o, k);
+                for (uint64_t m = S->members_off[k]; m < S->members_off[k + 1]; ++m) { o.push_back('\t'); add_header(o, S, S->members[m]); }
+                o.push_back('\n');
+            }
+        });
+        if (!ok) { pgx_set_error("cannot write %s", names_path); return PGX_ERR_INVALID; }
     }
     if (nr_out_path) {
-        Out o(nr_out_path);
-        if (!o.ok()) { pgx_set_error("cannot write %s", nr_out_path); return PGX_ERR_INVALID; }
-        for (uint64_t k = 0; k < G; ++k) {
-            if (cluster[k] < 0) continue;
-            o.put('>'); put_name(o, k); o.put('\n');
-            put_body(o, S, S->rec(S->rep_of_group[k]));
-        }
-        if (!o.close()) { pgx_set_error("write to %s failed", nr_out_path); return PGX_ERR_INVALID; }
+        const bool ok = parallel_write(nr_out_path, G, T, [&](uint64_t b, uint64_t e, std::string &o) {
+            uint64_t bytes = 0;
+            for (uint64_t k = b; k < e; ++k) if (cluster[k] >= 0) bytes += S->rec(S->rep_of_group[k]).body_len + 40;
+            o.reserve(bytes);
+            for (uint64_t k = b; k < e; ++k) {
+                if (cluster[k] < 0) continue;
+                o.push_back('>'); name_of(o, k); o.push_back('\n');
+                add_body(o, S, S->rec(S->rep_of_group[k]));
+            }
+        });
+        if (!ok) { pgx_set_error("cannot write %s", nr_out_path); return PGX_ERR_INVALID; }
     }
     return PGX_OK;
 }

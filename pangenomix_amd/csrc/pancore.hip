@@ -23,8 +23,12 @@
 //   partial[stripe*wps+v][iter][j]. A second, tiny kernel sums the 8*wps partials.
 //   No atomics, bit-reproducible.
 //
-// Roofline: HBM/L2 streaming. Algorithmic bytes per iteration = S*ceil(G/64)*8 + 2*S*4 (+S*4
-// for the permutation), SURVEY §8d.
+// Roofline: the aggregate L2 (the matrix is L2-resident by design). Algorithmic bytes per iteration =
+// S*ceil(G/64)*8 + 2*S*4 (+S*4 for the permutation), SURVEY §8d.
+// Tried in round 2 and not kept: staging 256-byte slices of all rows in LDS (100 KB per workgroup, 16
+// iterations per workgroup, half-wave per iteration, LDS accumulators): 0.78 ms against this kernel's
+// 0.68 ms -- one workgroup per CU leaves two waves per SIMD to hide a chain of two LDS reads per step
+// (software-pipelined two deep: no change). DESIGN.md section 6.
 #include <algorithm>
 #include <cstdlib>
 
@@ -149,120 +153,6 @@ __global__ __launch_bounds__(PC_WAVES * 64) void pan_core_sweep_kernel(
 }
 
 
-// ----------------------------------------------------------------------------------------
-// pan/core from LDS: the kernel used whenever all genome rows of a 256-byte slice fit a workgroup's LDS
-// ----------------------------------------------------------------------------------------
-// pan_core_sweep_kernel above re-reads the whole matrix from L2 in every iteration (7.5 GB per launch at
-// 150,000 x 400 x 1000: 0.31 of the aggregate L2 peak). Here a workgroup stages a SLICE -- the same 256
-// bytes (2048 genes) of all S rows: 100 KB at S = 400 -- in LDS once and runs 16 iterations over it, one
-// per half-wave: per step one broadcast read of the permutation entry and one conflict-free ds_read_b64 per
-// lane (a half-wave reads the row's 256 contiguous bytes), OR / AND / popcount, five DPP adds, and one LDS
-// add into the workgroup's (iteration, step) accumulators. The workgroup walks its group of <= 31 slices
-// (block b: slice group b % n_sg -- one XCD's L2 holds one group -- iterations 16 (b / n_sg) ...), so the matrix
-// crosses the L2 -> LDS path n_iter / 16 times instead of n_iter times and only n_sg partial tables are
-// written (8 x 1.6 MB at the benchmark's size; they were 24 x 1.6 MB).
-constexpr int LD_THREADS = 512;
-constexpr int LD_ITERS = LD_THREADS / 32;   // iterations per workgroup: one per half-wave
-constexpr uint32_t LD_SLICE = 256;          // bytes of a row per slice
-constexpr uint32_t LD_MAX_SLICES = 31;      // per group: 31 x 2048 genes stay below the 16-bit halves of an accumulator
-
-__device__ __forceinline__ uint32_t halfwave_sum_u32(uint32_t x) {   // lanes 16-31 / 48-63 end up with their half's sum
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);  // row_half_mirror
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);  // row_mirror
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);  // row_bcast15 -> rows 1,3
-    return x;
-}
-
-__global__ __launch_bounds__(LD_THREADS) void pan_core_lds_kernel(const char *__restrict__ bits, uint32_t stride_bytes,
-                                                                  const int32_t *__restrict__ perms, uint32_t n_iter,
-                                                                  uint32_t S, uint32_t S4, uint32_t n_slices, uint32_t n_sg,
-                                                                  uint32_t *__restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    char *rowbuf = lds;                                                              // S x 256 bytes
-    uint16_t *permbuf = reinterpret_cast<uint16_t *>(lds + (size_t)S * LD_SLICE);    // 16 x S4 (S rounded up to 4)
-    uint32_t *acc = reinterpret_cast<uint32_t *>(lds + (size_t)S * LD_SLICE + (size_t)LD_ITERS * S4 * 2);   // 16 x S4
-    const uint32_t tid = threadIdx.x, hw = tid >> 5, l32 = tid & 31u;
-    const uint32_t sg = blockIdx.x % n_sg, ig = blockIdx.x / n_sg;
-    const uint32_t s_lo = (uint32_t)((uint64_t)sg * n_slices / n_sg), s_hi = (uint32_t)((uint64_t)(sg + 1) * n_slices / n_sg);
-    const uint32_t iter = ig * LD_ITERS + hw;
-    const bool live = iter < n_iter;
-    for (uint32_t i = tid; i < LD_ITERS * S4; i += LD_THREADS) {
-        const uint32_t it = ig * LD_ITERS + i / S4, j = i % S4;
-        permbuf[i] = (it < n_iter && j < S) ? (uint16_t)perms[(size_t)it * S + j] : (uint16_t)0;
-        acc[i] = 0u;
-    }
-    const uint16_t *prow = permbuf + hw * S4;
-    uint32_t *arow = acc + hw * S4;
-    for (uint32_t slice = s_lo; slice < s_hi; ++slice) {
-        __syncthreads();   // the slice before has been consumed (and permbuf / acc are set up)
-        const uint32_t off = slice * LD_SLICE;
-        for (uint32_t c = tid; c < S * (LD_SLICE / 16); c += LD_THREADS) {   // 16 threads per row, coalesced 256-byte segments
-            const uint32_t r = c >> 4, ch = (c & 15u) * 16u;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (off + ch < stride_bytes) v = *reinterpret_cast<const uint4 *>(bits + (size_t)r * stride_bytes + off + ch);
-            *reinterpret_cast<uint4 *>(rowbuf + r * LD_SLICE + ch) = v;
-        }
-        __syncthreads();
-        if (!live) continue;
-        unsigned long long o = 0ull, a = ~0ull;
-        const char *lane_col = rowbuf + l32 * 8u;
-        // Four steps per trip, software-pipelined two deep: a step is a chain of two LDS reads (permutation
-        // entry -> row), and with one workgroup per CU there are only two waves per SIMD to hide them, so the
-        // entries of trip g+2 and the rows of trip g+1 are requested before trip g is folded.
-        auto rows_of = [&](uint2 p4, unsigned long long v[4]) {
-            v[0] = *reinterpret_cast<const unsigned long long *>(lane_col + (p4.x & 0xFFFFu) * LD_SLICE);
-            v[1] = *reinterpret_cast<const unsigned long long *>(lane_col + (p4.x >> 16) * LD_SLICE);
-            v[2] = *reinterpret_cast<const unsigned long long *>(lane_col + (p4.y & 0xFFFFu) * LD_SLICE);
-            v[3] = *reinterpret_cast<const unsigned long long *>(lane_col + (p4.y >> 16) * LD_SLICE);
-        };
-        unsigned long long vc[4], vn[4];
-        uint2 pn = *reinterpret_cast<const uint2 *>(prow + (S4 > 4 ? 4 : 0));
-        rows_of(*reinterpret_cast<const uint2 *>(prow), vc);
-        for (uint32_t j = 0; j < S4; j += 4) {
-            rows_of(pn, vn);                                                     // rows of the next trip
-            const uint32_t j2 = j + 8 < S4 ? j + 8 : 0;                          // (past the end: any valid entry)
-            const uint2 pn2 = *reinterpret_cast<const uint2 *>(prow + j2);       // entries of the trip after next
-            uint32_t c[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                o |= vc[t]; a &= vc[t];
-                c[t] = (uint32_t)__popcll(o) | ((uint32_t)__popcll(a) << 16);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) c[t] = halfwave_sum_u32(c[t]);
-            if (l32 == 31u) {   // (steps >= S of the padded tail land in accumulators that are never stored)
-                uint4 *dst = reinterpret_cast<uint4 *>(arow + j);
-                uint4 t4 = *dst;
-                t4.x += c[0]; t4.y += c[1]; t4.z += c[2]; t4.w += c[3];
-                *dst = t4;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) vc[t] = vn[t];
-            pn = pn2;
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < LD_ITERS * S4; i += LD_THREADS) {
-        const uint32_t it = ig * LD_ITERS + i / S4, j = i % S4;
-        if (it < n_iter && j < S) partial[((size_t)sg * n_iter + it) * S + j] = acc[i];
-    }
-}
-
-struct LdsGeom { uint32_t S4, n_slices, n_sg; size_t lds_bytes; bool ok; };
-LdsGeom make_lds_geom(uint32_t n_genes, uint32_t n_genomes) {
-    LdsGeom g;
-    g.S4 = (n_genomes + 3u) & ~3u;
-    const uint32_t stride_bytes = pgx_bitmap_stride_words(n_genes) * 8u;
-    g.n_slices = (stride_bytes + LD_SLICE - 1) / LD_SLICE;
-    g.n_sg = std::max<uint32_t>(PC_STRIPES, ((g.n_slices + LD_MAX_SLICES - 1) / LD_MAX_SLICES + PC_STRIPES - 1) / PC_STRIPES * PC_STRIPES);
-    if (g.n_sg > g.n_slices) g.n_sg = g.n_slices;
-    g.lds_bytes = (size_t)n_genomes * LD_SLICE + (size_t)LD_ITERS * g.S4 * 6;
-    g.ok = g.lds_bytes <= 160 * 1024 && n_genomes <= 65535 && n_genomes >= 1;
-    return g;
-}
-
 __global__ __launch_bounds__(256) void pan_core_reduce_kernel(const uint32_t *__restrict__ partial,
                                                              uint32_t n_partials, size_t n_out,
                                                              int32_t *__restrict__ out_pan,
@@ -341,9 +231,7 @@ uint32_t pgx_bitmap_stride_words(uint32_t n_genes) {
 
 size_t pgx_pan_core_workspace_bytes(uint32_t n_genes, uint32_t n_genomes, uint32_t n_iter) {
     const PanCoreGeom g = make_geom(n_genes);
-    const LdsGeom l = make_lds_geom(n_genes, n_genomes);
-    const uint32_t partials = std::max<uint32_t>(g.partials, l.ok ? l.n_sg : 0u);
-    return (size_t)partials * n_iter * n_genomes * sizeof(uint32_t);
+    return (size_t)g.partials * n_iter * n_genomes * sizeof(uint32_t);
 }
 
 int pgx_presence_bitmap_dev(pgx_ctx *ctx, const int32_t *d_rows, const int32_t *d_genomes,
@@ -415,24 +303,8 @@ int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uin
     PGX_REQUIRE(((uintptr_t)d_bits & 15u) == 0, "bitmap must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     const PanCoreGeom g = make_geom(n_genes);
-    const LdsGeom l = make_lds_geom(n_genes, n_genomes);
-    uint32_t n_partials = g.partials;
-    static const bool force_l2 = std::getenv("PGX_PANCORE_L2") != nullptr;   // (the L2 kernel, for comparison runs)
-    if (l.ok && !force_l2) {
-        // all rows of a slice fit a workgroup's LDS: the matrix is staged there (see pan_core_lds_kernel)
-        static bool attr_set = false;
-        if (!attr_set) {
-            PGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pan_core_lds_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        const uint64_t blocks = (uint64_t)((n_iter + LD_ITERS - 1) / LD_ITERS) * l.n_sg;
-        PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
-        ProfScope prof(ctx, "pan_core_sweep_kernel", stream);
-        pan_core_lds_kernel<<<(uint32_t)blocks, LD_THREADS, l.lds_bytes, stream>>>(
-            (const char *)d_bits, g.stride * 8, d_perms, n_iter, n_genomes, l.S4, l.n_slices, l.n_sg, (uint32_t *)d_workspace);
-        n_partials = l.n_sg;
-    } else {
+    const uint32_t n_partials = g.partials;
+    {
         const uint64_t items = (uint64_t)n_iter * g.wps;  // per stripe
         const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * PC_STRIPES;
         PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");

@@ -283,11 +283,11 @@ def _first_occurrence_coo(rows, cols, n_rows, n_cols):
     """COO with ones, duplicates dropped, triples in order of first insertion:
     the order scipy's dok_matrix.tocoo() yields for the reference's loop
     (:649-650), pinned by tests/golden/cds."""
+    import pandas as pd
     rows = np.asarray(rows, dtype=np.int64)
     cols = np.asarray(cols, dtype=np.int64)
     flat = rows * max(n_cols, 1) + cols
-    _, first = np.unique(flat, return_index=True)
-    first.sort()
+    first = np.flatnonzero(~pd.Series(flat).duplicated().values)     # hash-based: linear, keeps the order
     data = np.ones(first.size, dtype=np.int64)
     return scipy.sparse.coo_matrix(
         (data, (rows[first].astype(np.int32), cols[first].astype(np.int32))),
