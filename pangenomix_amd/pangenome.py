@@ -12,6 +12,7 @@ Drop-in mirror of the reference entry points in pangenomix/pangenome.py
      build_genetic_feature_tables  allele x genome, gene x genome   (H4)
      LightSparseDataFrame.to_npz   .npz + .labels.txt               (H5)
      extract_noncoding             GFF+FNA -> feature FASTA         (H6)
+  build_upstream/downstream/proximal_pangenome   5'/3' UTR pangenomes
 
 Same names, positional order, defaults, intermediate files and return values.
 The only behavioural differences are deliberate: a failing
@@ -614,3 +615,224 @@ def build_noncoding_pangenome(genome_data, output_dir, name='Test', flanking=(0,
     print('Saving', gene_npz, '...')
     df_genes.to_npz(gene_npz)
     return df_alleles, df_genes
+
+# ---------------------------------------------------------------------------
+# proximal (5'/3' UTR) pangenomes (reference :743-1184, :2027-2038)
+# ---------------------------------------------------------------------------
+# Host-only rows: exact-match grouping per gene instead of clustering, the same table machinery. Mirrored
+# statement by statement where Python's own semantics decide the outcome (negative slice starts at contig
+# ends, dictionary insertion order, the unconditional last record); tests/golden/proximal holds what the
+# reference produced.
+def __load_feature_to_allele__(allele_names):
+    """{'fig|<genome>.peg.#': allele} from <name>_allele_names.tsv: every synonym of a line, cut to its
+    first two '|' fields (reference :2027-2038)."""
+    feat_to_allele = {}
+    with open(allele_names, 'r') as f:
+        for line in f:
+            data = line.strip().split('\t')
+            for synonym in data[1:]:
+                feat_to_allele['|'.join(synonym.split('|')[:2])] = data[0]
+    return feat_to_allele
+
+
+def extract_proximal_sequences(genome_gff, genome_fna, proximal_out, limits, max_overlap, side,
+                               feature_to_allele=None, allele_names=None, include_fragments=False):
+    """Nucleotides upstream / downstream of every mapped GFF feature (PATRIC flavour: contig column
+    'accn|<contig>', ID attribute) written as '<ID>_<side>(<limits>[,<max_overlap>])' records
+    (reference :1038-1184). limits = (-X, Y): upstream X bases before the start codon + the first Y coding
+    bases; downstream the last X coding bases + Y bases after the stop. max_overlap >= 0 truncates a region
+    that runs into the neighbouring CDS on the same strand (GFF order). Regions cut off by a contig end are
+    dropped unless include_fragments."""
+    neighbours = {}      # contig -> strand -> (start, stop) -> (end of the CDS before, start of the CDS after)
+    if max_overlap >= 0:
+        placed = {}
+        with open(genome_gff, 'r') as f_gff:
+            for line in f_gff:
+                line = line.strip()
+                if len(line) > 0 and line[0] != '#':
+                    contig, _src, ftype, start, stop, _score, strand, _phase, _attr = line.split('\t')
+                    if ftype == 'CDS':
+                        contig = contig.split('|')[-1]
+                        placed.setdefault(contig, {'+': [], '-': []})[strand].append((int(start) - 1, int(stop)))
+        for contig, by_strand in placed.items():
+            neighbours[contig] = {'+': {}, '-': {}}
+            for strand, feats in by_strand.items():
+                for i, feat in enumerate(feats):
+                    left = -np.inf if i == 0 else feats[i - 1][1]
+                    right = np.inf if i == len(feats) - 1 else feats[i + 1][0]
+                    neighbours[contig][strand][feat] = (left, right)
+
+    contigs = load_sequences_from_fasta(genome_fna, header_fxn=lambda x: x.split()[0])
+    if feature_to_allele:
+        feat_to_allele = feature_to_allele
+    elif allele_names:
+        feat_to_allele = __load_feature_to_allele__(allele_names)
+    else:
+        feat_to_allele = None
+
+    params = (limits[0], limits[1], max_overlap) if max_overlap >= 0 else limits
+    footer = '_' + side + str(params).replace(' ', '')
+    coding_length = limits[1] if side == 'upstream' else -limits[0]
+    count = 0
+    with open(proximal_out, 'w+') as f_prox, open(genome_gff, 'r') as f_gff:
+        for line in f_gff:
+            line = line.strip()
+            if len(line) == 0 or line[0] == '#':
+                continue
+            contig, _src, _ftype, start, stop, _score, strand, _phase, attr_raw = line.split('\t')
+            contig = contig.split('|')[-1]
+            start, stop = int(start) - 1, int(stop)
+            attrs = {}
+            for entry in attr_raw.split(';'):
+                k, v = entry.split('=')
+                attrs[k] = v
+            gffid = attrs['ID']
+            if contig not in contigs:
+                continue
+            # (evaluated in the reference's order: without a mapping the membership test itself fails, :1166)
+            if not (gffid in feat_to_allele or feat_to_allele is None):
+                continue
+            seq = contigs[contig]
+            anchor = start if (side, strand) in (('upstream', '+'), ('downstream', '-')) else stop
+            lo, hi = limits if strand == '+' else (-limits[1], -limits[0])
+            utr_start, utr_stop = anchor + lo, anchor + hi
+            if max_overlap >= 0:
+                left, right = neighbours[contig][strand][(start, stop)]
+                if utr_start < left - max_overlap:
+                    utr_start = left - max_overlap
+                if utr_stop > right + max_overlap:
+                    utr_stop = right + max_overlap
+            proximal = seq[utr_start:utr_stop].strip()      # (a negative start counts from the contig's end, as there)
+            if strand == '-':
+                proximal = reverse_complement(proximal)
+            is_fragment = utr_start < 0 or utr_stop > len(seq)
+            if len(proximal) > coding_length and (not is_fragment or include_fragments):
+                f_prox.write('>' + gffid + footer + '\n' + proximal + '\n')
+                count += 1
+    print('Loaded', side, 'sequences:', count)
+
+
+def extract_upstream_sequences(genome_gff, genome_fna, upstream_out, limits=(-50, 3), max_overlap=-1,
+                               feature_to_allele=None, allele_names=None, include_fragments=False):
+    """Reference :1021-1029."""
+    extract_proximal_sequences(genome_gff, genome_fna, proximal_out=upstream_out, limits=limits, max_overlap=max_overlap,
+                               side='upstream', feature_to_allele=feature_to_allele, allele_names=allele_names,
+                               include_fragments=include_fragments)
+
+
+def extract_downstream_sequences(genome_gff, genome_fna, downstream_out, limits=(-3, 50), max_overlap=-1,
+                                 feature_to_allele=None, allele_names=None, include_fragments=False):
+    """Reference :1032-1040."""
+    extract_proximal_sequences(genome_gff, genome_fna, proximal_out=downstream_out, limits=limits, max_overlap=max_overlap,
+                               side='downstream', feature_to_allele=feature_to_allele, allele_names=allele_names,
+                               include_fragments=include_fragments)
+
+
+def consolidate_proximal(genome_proximals, nr_proximal_out, feature_to_allele, side, output_format='lsdf'):
+    """Non-redundant proximal sequences PER GENE (<name>_C#U# upstream, <name>_C#D# downstream; the number
+    is the order of first appearance within the gene) and the proximal x genome table (reference :900-1018).
+    Files are taken in sorted order; the genome is the file name up to '_<side>'."""
+    letter = VARIANT_TYPES[side]
+    variants = {}        # gene -> {sequence: number}
+    per_genome = {}      # genome -> {proximal id: 1}, insertion order = first appearance
+    genome_order = []
+    ids = set()
+    with open(nr_proximal_out, 'w+') as f_nr:
+        def record(header, seq, genome):
+            feature = header.split('_' + side + '(')[0]
+            gene = __get_gene_from_allele__(feature_to_allele[feature])
+            known = variants.setdefault(gene, {})
+            is_new = seq not in known
+            if is_new:
+                known[seq] = len(known)
+            prox_id = gene + letter + str(known[seq])
+            ids.add(prox_id)
+            per_genome[genome][prox_id] = 1
+            if is_new:
+                f_nr.write('>' + prox_id + '\n' + seq + '\n')
+        for path in sorted(genome_proximals):
+            genome = path.split('/')[-1].split('_' + side)[0]
+            per_genome[genome] = {}
+            genome_order.append(genome)
+            header, seq = '', ''
+            with open(path, 'r') as f:
+                for line in f.readlines():
+                    if line[0] == '>':
+                        if len(seq) > 0:
+                            record(header, seq, genome)
+                        header, seq = line[1:].strip(), ''
+                    else:
+                        seq += line.strip()
+            record(header, seq, genome)          # the last record, unconditionally (:975-990)
+    print('Sparsifying', side, 'table...')
+    prox_order = sorted(ids)
+    index_of = {p: i for i, p in enumerate(prox_order)}
+    rows, cols = [], []
+    for genome_i, genome in enumerate(genome_order):
+        for prox_id in per_genome[genome]:
+            rows.append(index_of[prox_id])
+            cols.append(genome_i)
+    print('Building binary matrix...')
+    data = _first_occurrence_coo(rows, cols, len(prox_order), len(genome_order))
+    if output_format == 'sparr':
+        raise NotImplementedError("output_format='sparr' is not supported (SURVEY App. B.8); use 'lsdf'")
+    return sparse_utils.LightSparseDataFrame(prox_order, genome_order, data)
+
+
+def build_proximal_pangenome(genome_data, allele_names, output_dir, limits, side, name='Test',
+                             include_fragments=False, max_overlap=-1, fastasort_path=None,
+                             output_format='lsdf', fna_output_footer='', overwrite_extract=False):
+    """Proximal-region pangenome relative to the gene clusters of build_cds_pangenome(): per genome
+    `<gffdir>/derived/<genome>_<side><footer>.fna`, then `<name>_nr_<side>.fna` and
+    `<name>_strain_by_<side>.npz` (reference :777-897)."""
+    output_format = _check_format(output_format)
+    print('Loading header-allele mapping...')
+    feature_to_allele = __load_feature_to_allele__(allele_names)
+    print('Extracting', side, 'sequences...')
+    genome_proximals = []
+    for i, (gff, fna) in enumerate(genome_data):
+        genome = __get_genome_from_filename__(gff)
+        gdir = '/'.join(gff.split('/')[:-1]) + '/' if '/' in gff else ''
+        prox_dir = gdir + 'derived/'
+        if not os.path.exists(prox_dir):
+            os.mkdir(prox_dir)
+        prox = prox_dir + genome + '_' + side + fna_output_footer + '.fna'
+        genome_proximals.append(prox)
+        if os.path.exists(prox) and not overwrite_extract:
+            print(i + 1, 'Using pre-existing', side, 'regions for', genome)
+        else:
+            print(i + 1, 'Extracting', side, 'regions for', genome)
+            extract_proximal_sequences(gff, fna, prox, limits=limits, side=side, feature_to_allele=feature_to_allele,
+                                       include_fragments=include_fragments, max_overlap=max_overlap)
+    print('Identifying non-redundant', side, 'sequences per gene...')
+    nr_out = _p(output_dir, name, '_nr_' + side + '.fna')
+    df_proximal = consolidate_proximal(genome_proximals, nr_out, feature_to_allele, side, output_format=output_format)
+    if fastasort_path:
+        print('Sorting sequences by header...')
+        with open(nr_out + '.tmp', 'w+') as f_sort:
+            sp.call(['./' + fastasort_path, nr_out], stdout=f_sort)
+        os.rename(nr_out + '.tmp', nr_out)
+    npz = _p(output_dir, name, '_strain_by_' + side) + '.npz'
+    print('Saving', npz, '...')
+    df_proximal.to_npz(npz)
+    return df_proximal
+
+
+def build_upstream_pangenome(genome_data, allele_names, output_dir, limits=(-50, 3), name='Test',
+                             include_fragments=False, max_overlap=-1, fastasort_path=None, output_format='lsdf',
+                             fna_output_footer='', overwrite_extract=False):
+    """5'UTR pangenome (reference :743-757)."""
+    return build_proximal_pangenome(genome_data, allele_names, output_dir, limits, side='upstream', name=name,
+                                    include_fragments=include_fragments, max_overlap=max_overlap,
+                                    fastasort_path=fastasort_path, output_format=output_format,
+                                    fna_output_footer=fna_output_footer, overwrite_extract=overwrite_extract)
+
+
+def build_downstream_pangenome(genome_data, allele_names, output_dir, limits=(-3, 50), name='Test',
+                               include_fragments=False, max_overlap=-1, fastasort_path=None, output_format='lsdf',
+                               fna_output_footer='', overwrite_extract=False):
+    """3'UTR pangenome (reference :761-775)."""
+    return build_proximal_pangenome(genome_data, allele_names, output_dir, limits, side='downstream', name=name,
+                                    include_fragments=include_fragments, max_overlap=max_overlap,
+                                    fastasort_path=fastasort_path, output_format=output_format,
+                                    fna_output_footer=fna_output_footer, overwrite_extract=overwrite_extract)

@@ -11,6 +11,9 @@ container (needs /root/reference; it never travels to the GPU box):
   core_genome.count_gene_occurence            core_genome.py:127-155   on tests/golden/cds/expected/*.npz
   core_genome.find_core_genes                 core_genome.py:107-124
   allele_identification.count_allele_occurence allele_identification.py:129-157
+  pangenome.build_upstream_pangenome / build_downstream_pangenome (-> build_proximal_pangenome,
+  extract_proximal_sequences, consolidate_proximal)  pangenome.py:743-1184   on small GFF + FNA genomes
+                                              written here (tests/golden/proximal)
 
 `pangenome_analysis` imports statsmodels.stats and the two consumer modules import Bio (Biopython) at
 module level; neither is installed and neither is used by the functions above, so EMPTY placeholder
@@ -36,6 +39,7 @@ for _name in ('statsmodels', 'statsmodels.stats', 'Bio', 'Bio.SeqIO'):
 sys.modules['statsmodels'].stats = sys.modules['statsmodels.stats']
 sys.modules['Bio'].SeqIO = sys.modules['Bio.SeqIO']
 
+import pangenomix.pangenome as ref_pg                     # noqa: E402
 import pangenomix.pangenome_analysis as ref_pa            # noqa: E402
 import pangenomix.core_genome as ref_cg                   # noqa: E402
 import pangenomix.allele_identification as ref_ai         # noqa: E402
@@ -74,5 +78,75 @@ def main():
     print('next: %d heaps tables, occurrence counts of %d genes / %d alleles' % (n, len(g), len(a)))
 
 
+def make_proximal():
+    import shutil
+    root = os.path.join(HERE, 'proximal')
+    if os.path.exists(root):
+        shutil.rmtree(root)
+    din, dexp = os.path.join(root, 'in'), os.path.join(root, 'expected')
+    os.makedirs(din)
+    os.makedirs(dexp)
+    rng = np.random.default_rng(77)
+    nt = np.array(list('ACGT'))
+    base = {c: ''.join(rng.choice(nt, n)) for c, n in (('c1', 900), ('c2', 520))}
+    # features: (contig, type, start, stop, strand, peg number); 1-based inclusive coordinates
+    feats = [('c1', 'CDS', 20, 140, '+', 1),      # upstream region cut off by the contig start
+             ('c1', 'CDS', 200, 320, '+', 2),
+             ('c1', 'CDS', 326, 450, '+', 3),     # 5 nt after peg.2: overlap truncation
+             ('c1', 'tRNA', 460, 530, '+', None),
+             ('c1', 'CDS', 560, 700, '-', 4),
+             ('c1', 'CDS', 760, 880, '-', 5),     # downstream of a minus-strand gene near... upstream cut by the contig end
+             ('c2', 'CDS', 60, 200, '-', 6),
+             ('c2', 'CDS', 260, 400, '+', 7),
+             ('c9', 'CDS', 10, 100, '+', 8)]      # contig missing from the FNA
+    genomes = ['p1', 'p2', 'p10']
+    names = {}
+    for gi, g in enumerate(genomes):
+        seqs = {c: list(s) for c, s in base.items()}
+        if gi >= 1:                                # variants: a change upstream of peg.2 and downstream of peg.7
+            seqs['c1'][170] = 'A' if seqs['c1'][170] != 'A' else 'C'
+            seqs['c2'][420] = 'G' if seqs['c2'][420] != 'G' else 'T'
+        if gi == 2:                                # and a third variant upstream of peg.2
+            seqs['c1'][180] = 'T' if seqs['c1'][180] != 'T' else 'G'
+        with open(os.path.join(din, g + '.fna'), 'w') as f:
+            for c, s_ in seqs.items():
+                s_ = ''.join(s_)
+                f.write('>%s   contig of %s\n' % (c, g))
+                f.write('\n'.join(s_[i:i + 70] for i in range(0, len(s_), 70)) + '\n')
+        with open(os.path.join(din, g + '.gff'), 'w') as f:
+            f.write('##gff-version 3\n\n')
+            for c, t, a, b, st, k in feats:
+                fid = 'fig|%s.peg.%d' % (g, k) if k else 'fig|%s.rna.1' % g
+                f.write('\t'.join(['accn|' + c, 'PATRIC', t, str(a), str(b), '.', st, '0', 'ID=%s;product=x y' % fid]) + '\n')
+                if k and not (g == 'p10' and k == 5):          # p10's peg.5 is not in the name table
+                    names.setdefault(k, []).append('%s|fam%d' % (fid, k))
+    with open(os.path.join(din, 'T_allele_names.tsv'), 'w') as f:
+        for k, heads in sorted(names.items()):
+            f.write('T_C%dA0\t%s\n' % (k + 8, '\t'.join(heads[:2])))      # C9.. C16: lexicographic order matters
+            if len(heads) > 2:
+                f.write('T_C%dA1\t%s\n' % (k + 8, heads[2]))
+    pairs = [(os.path.join(din, g + '.gff'), os.path.join(din, g + '.fna')) for g in genomes]
+    runs = {'upstream': dict(fn=ref_pg.build_upstream_pangenome, kw={}),
+            'downstream': dict(fn=ref_pg.build_downstream_pangenome, kw={}),
+            'upstream_ov5': dict(fn=ref_pg.build_upstream_pangenome,
+                                 kw=dict(max_overlap=5, include_fragments=True, fna_output_footer='_ov5', name='O'))}
+    printed = {}
+    for tag, r in runs.items():
+        out = os.path.join(dexp, tag)
+        os.makedirs(out)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            r['fn'](pairs, os.path.join(din, 'T_allele_names.tsv'), out, **r['kw'])
+        printed[tag] = buf.getvalue().replace(din, '<in>').replace(out, '<out>')
+        side = 'upstream' if 'up' in tag else 'downstream'
+        for g in genomes:                          # the per-genome extracts land next to the inputs: move them
+            src = os.path.join(din, 'derived', '%s_%s%s.fna' % (g, side, r['kw'].get('fna_output_footer', '')))
+            shutil.move(src, os.path.join(out, os.path.basename(src)))
+    shutil.rmtree(os.path.join(din, 'derived'))
+    json.dump(printed, open(os.path.join(dexp, 'stdout.json'), 'w'), indent=0)
+    print('proximal: %d runs on %d genomes' % (len(runs), len(genomes)))
+
+
 if __name__ == '__main__':
     main()
+    make_proximal()
