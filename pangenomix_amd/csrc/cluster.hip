@@ -494,22 +494,27 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             atomicMin(&W.hminc[h], code);
         }
     };
-    // Two rounds of 64 words per trip: the loads of both rounds (word codes -> bit-map probes -> index
-    // lines) are issued before either round's entries are processed. The walk is bound by the latency of
-    // these dependent gathers at the occupancy LDS allows (16 waves per CU), so twice the lines in flight
-    // per wave is what shortens it.
-    struct Round { uint32_t code, mq; uint4 la, lb, lc, ld; };
-    auto process = [&](const Round &R) {
+    for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+        const uint32_t w = w0 + lane;
+        bool live = w < nw;
+        const uint32_t code = live ? S.wcode[o + w] : 0u;
+        const uint32_t mq = live ? S.wmult[o + w] : 0u;
+        if (NEWONLY && live) live = (A.newbits[code >> 5] >> (code & 31u)) & 1u;
+        uint4 la = make_uint4(0u, 0u, 0u, 0u), lb = la, lc = la, ld = la;
+        if (live) {
+            const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + code);
+            la = lp[0]; lb = lp[1]; lc = lp[2]; ld = lp[3];
+        }
         // line = { len, ovf, len_prev, epoch | pending, e0, e1, e2 | e3..e6 | e7..e10 }
-        const uint32_t hi = R.la.x;
-        const uint32_t lo = NEWONLY ? (R.la.w == A.epoch ? R.la.z : hi) : 0u;
+        const uint32_t hi = la.x;
+        const uint32_t lo = NEWONLY ? (la.w == A.epoch ? la.z : hi) : 0u;
         const uint32_t hi_in = hi < kInline ? hi : kInline;
         for (uint32_t j = lo; j < hi_in; ++j) {
-            uint32_t e = R.lb.y;                     // entry j, picked from the line's registers
-            e = j == 1 ? R.lb.z : e; e = j == 2 ? R.lb.w : e; e = j == 3 ? R.lc.x : e; e = j == 4 ? R.lc.y : e;
-            e = j == 5 ? R.lc.z : e; e = j == 6 ? R.lc.w : e; e = j == 7 ? R.ld.x : e; e = j == 8 ? R.ld.y : e;
-            e = j == 9 ? R.ld.z : e; e = j == 10 ? R.ld.w : e;
-            entry_visit(e, R.code, R.mq);
+            uint32_t e = lb.y;                     // entry j, picked from the line's registers
+            e = j == 1 ? lb.z : e; e = j == 2 ? lb.w : e; e = j == 3 ? lc.x : e; e = j == 4 ? lc.y : e;
+            e = j == 5 ? lc.z : e; e = j == 6 ? lc.w : e; e = j == 7 ? ld.x : e; e = j == 8 ? ld.y : e;
+            e = j == 9 ? ld.z : e; e = j == 10 ? ld.w : e;
+            entry_visit(e, code, mq);
         }
         // lists longer than the line: their pool parts are flattened into one run of entries that the whole
         // wave walks, one entry per lane and step, whatever the lists' lengths (a list of one new entry
@@ -521,7 +526,7 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             uint32_t incl = cnt_l;
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if ((int)lane >= d) incl += y; }
             const uint32_t total = __shfl(incl, 63);
-            W.lq[lane] = make_uint4(R.la.y + 1u + (from - kInline), incl - cnt_l, R.code, R.mq);
+            W.lq[lane] = make_uint4(la.y + 1u + (from - kInline), incl - cnt_l, code, mq);
             W.pref[lane] = incl;
             wave_lds_sync();
             for (uint32_t t = lane; t < total; t += 64) {
@@ -532,32 +537,6 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             }
             __builtin_amdgcn_wave_barrier();
         }
-    };
-    for (uint32_t w0 = 0; w0 < nw; w0 += 128) {
-        Round R[2];
-        bool live[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t w = w0 + 64u * h + lane;
-            live[h] = w < nw;
-            R[h].code = live[h] ? S.wcode[o + w] : 0u;
-            R[h].mq = live[h] ? S.wmult[o + w] : 0u;
-        }
-        if (NEWONLY) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (live[h]) live[h] = (A.newbits[R[h].code >> 5] >> (R[h].code & 31u)) & 1u;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            R[h].la = R[h].lb = R[h].lc = R[h].ld = make_uint4(0u, 0u, 0u, 0u);
-            if (live[h]) {
-                const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + R[h].code);
-                R[h].la = lp[0]; R[h].lb = lp[1]; R[h].lc = lp[2]; R[h].ld = lp[3];
-            }
-        }
-        process(R[0]);
-        if (w0 + 64u < nw) process(R[1]);
     }
 }
 
