@@ -106,7 +106,7 @@ struct DevSeqs {
     const uint8_t *res;     // residue indices, sorted order, concatenated
     const uint64_t *off;    // [n+1]
     const uint32_t *len;    // [n]
-    const uint32_t *wcode;  // distinct word codes, ascending, at off[k]
+    const uint32_t *wcode;  // distinct word codes at off[k] (no particular order)
     const uint16_t *wmult;  // multiplicities
     const uint32_t *wcnt;   // [n] number of distinct words
     // Nucleotide clustering with both strands stores the reverse complement of sequence k as
@@ -279,6 +279,67 @@ __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restric
     }
 }
 
+// The same list for sequences of up to 2048 words (nearly all of them) WITHOUT sorting: nothing downstream
+// needs the codes in order -- candidates are ordered by an explicit key, the index keeps no order -- only the
+// distinct codes and how often each occurs. The words are inserted into an open-addressing table in LDS
+// (twice the capacity; compare-and-swap on the code, atomic add on the count) and the occupied slots are
+// written out in slot order. Four barriers instead of the bitonic network's 45 stages.
+template <int NCAP, int THREADS>
+__global__ __launch_bounds__(THREADS) void words_hash_kernel(const uint8_t *__restrict__ res,
+                                                             const uint64_t *__restrict__ off,
+                                                             const uint32_t *__restrict__ len, uint32_t k0,
+                                                             uint32_t k1, int word_len, int base, int nt,
+                                                             uint32_t *__restrict__ wcode,
+                                                             uint16_t *__restrict__ wmult,
+                                                             uint32_t *__restrict__ wcnt) {
+    constexpr uint32_t SLOTS = 2 * NCAP;
+    __shared__ uint32_t hk[SLOTS];
+    __shared__ uint32_t hc[SLOTS];
+    __shared__ uint32_t part[THREADS];
+    const uint32_t k = k0 + blockIdx.x;
+    if (k >= k1) return;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t o = off[k];
+    const uint8_t *s = res + o;
+    const uint32_t nw = len[k] - (uint32_t)word_len + 1u;
+    for (uint32_t i = tid; i < SLOTS; i += THREADS) { hk[i] = kSentinel; hc[i] = 0u; }
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += THREADS) {
+        uint32_t key = 0;
+        bool bad = false;
+        for (int t = 0; t < word_len; ++t) { key = key * (uint32_t)base + s[i + t]; bad |= s[i + t] >= base; }
+        if (nt && bad) continue;                          // words containing N are skipped
+        uint32_t slot = (key * 0x9E3779B1u) >> 7 & (SLOTS - 1u);
+        for (;;) {                                         // (at most half the slots are ever taken)
+            const uint32_t cur = hk[slot];
+            if (cur == key) break;
+            if (cur == kSentinel) {
+                const uint32_t was = atomicCAS(&hk[slot], kSentinel, key);
+                if (was == kSentinel || was == key) break;
+            }
+            slot = (slot + 1u) & (SLOTS - 1u);
+        }
+        atomicAdd(&hc[slot], 1u);
+    }
+    __syncthreads();
+    constexpr uint32_t C = SLOTS / THREADS;               // slots per thread, contiguous
+    const uint32_t beg = tid * C;
+    uint32_t mine = 0;
+    for (uint32_t i = beg; i < beg + C; ++i) mine += hk[i] != kSentinel;
+    part[tid] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < THREADS; d <<= 1) {          // inclusive Hillis-Steele scan
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t idx = part[tid] - mine;
+    if (tid == THREADS - 1) wcnt[k] = part[tid];
+    for (uint32_t i = beg; i < beg + C; ++i)
+        if (hk[i] != kSentinel) { wcode[o + idx] = hk[i]; wmult[o + idx] = (uint16_t)hc[i]; ++idx; }
+}
+
 // ----------------------------------------------------------------------------------------
 // the word index: one 64-byte line per word code, appended to when representatives are created
 // ----------------------------------------------------------------------------------------
@@ -395,7 +456,7 @@ __global__ __launch_bounds__(256) void index_write_kernel(DevSeqs S, const uint3
 // Every visited entry with r < q counts as a posting visit of the sequential rule, whatever the
 // query's state; final queries (`done`) only count.
 constexpr int kFB = 1024;          // buckets per wave
-constexpr int kFH = 128;           // exact table slots per wave (with 1024 buckets: 28 KB of LDS per workgroup, five per CU)
+constexpr int kFH = 256;           // exact table slots per wave
 constexpr uint32_t kFProbe = 24;   // probes before the exact table counts as full
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kFWork = 32;         // residue-class work list per wave
@@ -425,15 +486,12 @@ struct FilterArgs {
 };
 
 // multiplicity of `code` in the word list of sequence r (present by construction of the index);
-// rare (the word is repeated in the query AND in the representative): kept out of line
+// rare (the word is repeated in the query AND in the representative): a scan, kept out of line
 __device__ __noinline__ uint32_t word_mult_of(const uint32_t *__restrict__ wcode, const uint16_t *__restrict__ wmult,
                                               uint64_t o, uint32_t n, uint32_t code) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (wcode[o + mid] < code) lo = mid + 1; else hi = mid;
-    }
-    return wmult[o + lo];
+    for (uint32_t i = 0; i < n; ++i)          // (word lists keep no order)
+        if (wcode[o + i] == code) return wmult[o + i];
+    return 1u;
 }
 
 __device__ __forceinline__ void wave_lds_sync() {   // LDS writes of this wave's lanes visible to all its lanes
@@ -450,7 +508,7 @@ struct FilterWave {   // a wave's private LDS
 
 // exact table: slot of representative r (inserted if absent), or kFH when the table is full
 __device__ __forceinline__ uint32_t exact_slot(uint32_t *hrep, uint32_t r) {
-    uint32_t h = (r * 0xC2B2AE35u) >> 25;         // 7 bits
+    uint32_t h = (r * 0xC2B2AE35u) >> 24;         // 8 bits
     for (uint32_t probe = 0; probe < kFProbe; ++probe) {
         const uint32_t cur = hrep[h];
         if (cur == r) return h;
@@ -541,7 +599,7 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
 }
 
 template <bool NT, bool NEWONLY>
-__global__ __launch_bounds__(256, 5) void filter_kernel(DevSeqs S, FilterArgs A) {
+__global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][kFB];
     __shared__ uint32_t s_hrep[4][kFH], s_hcnt[4][kFH], s_hminc[4][kFH];
     __shared__ uint4 s_lq[4][64];
@@ -698,30 +756,12 @@ __global__ __launch_bounds__(kSelThreads) void select_block_kernel(const unsigne
 
 // Start of a discovery round: the window's still-open members (not final, no accepted
 // representative), and where the round's segment of the new-representative list begins.
-// IN ORDER (one workgroup, consecutive members per thread, exclusive scan): the discovery kernels then work
-// on one chunk's tag table at a time, which stays in the caches, instead of on all 32 of them (512 MB) at
-// once -- with the list in arrival order of an atomic counter they fetched 0.4-0.9 GB per launch from HBM.
-__global__ __launch_bounds__(kSelThreads) void list_open_kernel(const unsigned long long *__restrict__ best,
-                                                               const uint8_t *__restrict__ done, uint32_t b0, uint32_t nb,
-                                                               uint32_t *__restrict__ ulist, uint32_t *__restrict__ n_open) {
-    __shared__ uint32_t part[kSelThreads];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (nb + kSelThreads - 1) / kSelThreads;
-    const uint32_t q0 = tid * per, q1 = min(nb, q0 + per);
-    uint32_t c = 0;
-    for (uint32_t q = q0; q < q1; ++q) c += !done[q] && best[q] == kNoBest;
-    part[tid] = c;
-    __syncthreads();
-    for (uint32_t d = 1; d < kSelThreads; d <<= 1) {
-        const uint32_t v = tid >= d ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t rank = part[tid] - c;
-    for (uint32_t q = q0; q < q1; ++q)
-        if (!done[q] && best[q] == kNoBest) ulist[rank++] = b0 + q;
-    if (tid == kSelThreads - 1) *n_open = part[tid];
+__global__ __launch_bounds__(256) void list_open_kernel(const unsigned long long *__restrict__ best,
+                                                       const uint8_t *__restrict__ done, uint32_t b0, uint32_t nb,
+                                                       uint32_t *__restrict__ ulist, uint32_t *__restrict__ n_open) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nb) return;
+    if (!done[q] && best[q] == kNoBest) ulist[atomicAdd(n_open, 1u)] = b0 + q;
 }
 // Discovery of certain representatives in time linear in the open members' words.
 //
@@ -1549,6 +1589,18 @@ static inline hipError_t spin_sync(hipStream_t st) {
 }
 
 template <int NCAP, int THREADS>
+int launch_words_hash(pgx_ctx *ctx, hipStream_t st, const uint8_t *res, const uint64_t *off, const uint32_t *len,
+                      uint32_t k0, uint32_t k1, int word_len, int base, int nt, uint32_t *wcode, uint16_t *wmult,
+                      uint32_t *wcnt) {
+    if (k1 <= k0) return PGX_OK;
+    ProfScope prof(ctx, "words_kernel", st);
+    words_hash_kernel<NCAP, THREADS><<<k1 - k0, THREADS, 0, st>>>(res, off, len, k0, k1, word_len, base, nt, wcode, wmult,
+                                                                  wcnt);
+    LAUNCH_CHECK();
+    return PGX_OK;
+}
+
+template <int NCAP, int THREADS>
 int launch_words(pgx_ctx *ctx, hipStream_t st, const uint8_t *res, const uint64_t *off, const uint32_t *len,
                  uint32_t k0, uint32_t k1, int word_len, int base, int nt, uint32_t *wcode, uint16_t *wmult,
                  uint32_t *wcnt) {
@@ -1870,8 +1922,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             const uint32_t o = half * n;
             if ((rc = launch_words<32768, 1024>(ctx, st, r8, o64, l32, o, o + k8, wl, base, nt, wc, wm, wn))) return rc;
             if ((rc = launch_words<8192, 1024>(ctx, st, r8, o64, l32, o + k8, o + k2, wl, base, nt, wc, wm, wn))) return rc;
-            if ((rc = launch_words<2048, 256>(ctx, st, r8, o64, l32, o + k2, o + k5, wl, base, nt, wc, wm, wn))) return rc;
-            if ((rc = launch_words<512, 128>(ctx, st, r8, o64, l32, o + k5, o + n, wl, base, nt, wc, wm, wn))) return rc;
+            if ((rc = launch_words_hash<2048, 256>(ctx, st, r8, o64, l32, o + k2, o + k5, wl, base, nt, wc, wm, wn))) return rc;
+            if ((rc = launch_words_hash<512, 128>(ctx, st, r8, o64, l32, o + k5, o + n, wl, base, nt, wc, wm, wn))) return rc;
         }
     }
     DevSeqs DS{d_res.as<uint8_t>(), d_off.as<uint64_t>(), d_len.as<uint32_t>(),
@@ -2072,14 +2124,14 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)max_chunks * n_codes * 4, st)); epoch_tag = 1; }
             zero_kernel<<<1024, 256, 0, st>>>(d_chunkbits.as<uint4>(), ((size_t)n_codes + 3) / 4);
             round_begin_kernel<<<1, 1, 0, st>>>(dc);
-            list_open_kernel<<<1, kSelThreads, 0, st>>>(d_best, d_done, b0, nb, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN);
+            list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN);
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "discover_kernels", st);
-                first_open_kernel<<<(nb + 3) / 4, 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
+                first_open_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
                                                                                  epoch_tag, d_first.as<uint32_t>(), n_codes,
                                                                                  d_chunkbits.as<uint32_t>(), chunks);
-                certain_kernel<<<(nb + 3) / 4, 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
+                certain_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
                                                                               both ? 1u : 0u, epoch_tag, d_first.as<uint32_t>(), n_codes,
                                                                               d_chunkbits.as<uint32_t>(), chunks,
                                                                               d_aan.as<int32_t>(), d_done, d_new_list.as<uint32_t>(),
