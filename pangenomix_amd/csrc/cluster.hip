@@ -456,7 +456,8 @@ __global__ __launch_bounds__(256) void index_write_kernel(DevSeqs S, const uint3
 // Every visited entry with r < q counts as a posting visit of the sequential rule, whatever the
 // query's state; final queries (`done`) only count.
 constexpr int kFB = 1024;          // buckets per wave
-constexpr int kFH = 256;           // exact table slots per wave
+constexpr int kFH = 256;           // exact table slots per wave (proteins)
+constexpr int kFHNt = 2048;        // ... nucleotides: one shared word makes a candidate, so a query's table holds most representatives it meets
 constexpr uint32_t kFProbe = 24;   // probes before the exact table counts as full
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 constexpr int kFWork = 32;         // residue-class work list per wave
@@ -506,9 +507,10 @@ struct FilterWave {   // a wave's private LDS
     uint32_t *pref;
 };
 
-// exact table: slot of representative r (inserted if absent), or kFH when the table is full
+// exact table: slot of representative r (inserted if absent), or FH when the table is full
+template <int FH>
 __device__ __forceinline__ uint32_t exact_slot(uint32_t *hrep, uint32_t r) {
-    uint32_t h = (r * 0xC2B2AE35u) >> 24;         // 8 bits
+    uint32_t h = ((r * 0xC2B2AE35u) >> 8) & (uint32_t)(FH - 1);
     for (uint32_t probe = 0; probe < kFProbe; ++probe) {
         const uint32_t cur = hrep[h];
         if (cur == r) return h;
@@ -516,15 +518,15 @@ __device__ __forceinline__ uint32_t exact_slot(uint32_t *hrep, uint32_t r) {
             const uint32_t was = atomicCAS(&hrep[h], kEmpty, r);
             if (was == kEmpty || was == r) return h;
         }
-        h = (h + 1u) & (kFH - 1u);
+        h = (h + 1u) & (uint32_t)(FH - 1);
     }
-    return (uint32_t)kFH;
+    return (uint32_t)FH;
 }
 
 // One walk over the words [0, nw) at `o` of a query strand. PASS2 = false: count into the buckets
 // (`visits`, `hot`); true: accumulate the representatives of hot buckets whose residue class is
 // (class_k, class_j) in the exact table (`full` when it overflows).
-template <bool NEWONLY, bool PASS2>
+template <bool NEWONLY, bool PASS2, int FH>
 __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &A, const FilterWave &W, uint32_t lane,
                                             uint64_t o, uint32_t nw, uint32_t q, uint32_t thr, bool count_only,
                                             uint32_t class_k, uint32_t class_j, uint32_t &visits, bool &hot,
@@ -546,8 +548,8 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
         } else {
             if (W.bucket[b] < thr) return;
             if (((((r ^ (r >> 15)) * 0x85EBCA6Bu) >> 9) & (class_k - 1u)) != class_j) return;
-            const uint32_t h = exact_slot(W.hrep, r);
-            if (h == (uint32_t)kFH) { full = true; return; }
+            const uint32_t h = exact_slot<FH>(W.hrep, r);
+            if (h == (uint32_t)FH) { full = true; return; }
             atomicAdd(&W.hcnt[h], c);
             atomicMin(&W.hminc[h], code);
         }
@@ -601,7 +603,8 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
 template <bool NT, bool NEWONLY>
 __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][kFB];
-    __shared__ uint32_t s_hrep[4][kFH], s_hcnt[4][kFH], s_hminc[4][kFH];
+    constexpr int FH = NT ? kFHNt : kFH;
+    __shared__ uint32_t s_hrep[4][FH], s_hcnt[4][FH], s_hminc[4][FH];
     __shared__ uint4 s_lq[4][64];
     __shared__ uint32_t s_pref[4][64];
     __shared__ uint2 s_work[4][kFWork];
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     const FilterWave W{s_bucket[wave], s_hrep[wave], s_hcnt[wave], s_hminc[wave], s_lq[wave], s_pref[wave]};
     uint2 *work = s_work[wave];
     for (uint32_t i = lane; i < kFB; i += 64) W.bucket[i] = 0u;
-    for (uint32_t i = lane; i < kFH; i += 64) { W.hrep[i] = kEmpty; W.hcnt[i] = 0u; W.hminc[i] = kSentinel; }
+    for (uint32_t i = lane; i < (uint32_t)FH; i += 64) { W.hrep[i] = kEmpty; W.hcnt[i] = 0u; W.hminc[i] = kSentinel; }
     wave_lds_sync();
 
     const uint32_t n_list = A.qlist ? *A.d_nq : 0u;
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         const uint32_t nw = S.wcnt[k];
         uint32_t visits = 0;
         bool hot = false, full = false;
-        filter_walk<NEWONLY, false>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full);
+        filter_walk<NEWONLY, false, FH>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full);
         wave_lds_sync();
         for (int d = 32; d > 0; d >>= 1) visits += __shfl_xor(visits, d);
         if (visits && lane == 0 && A.count_visits) {
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
                 const uint2 cls = work[n_work - 1];
                 --n_work;
                 full = false;
-                filter_walk<NEWONLY, true>(S, A, W, lane, o, nw, q, thr, false, cls.x, cls.y, visits, hot, full);
+                filter_walk<NEWONLY, true, FH>(S, A, W, lane, o, nw, q, thr, false, cls.x, cls.y, visits, hot, full);
                 wave_lds_sync();
                 const bool over = __ballot(full) != 0ull;
                 if (over) {
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
                         n_work += 4;
                     }
                 }
-                for (uint32_t h = lane; h < (uint32_t)kFH; h += 64) {
+                for (uint32_t h = lane; h < (uint32_t)FH; h += 64) {
                     const uint32_t r = W.hrep[h];
                     if (r == kEmpty) continue;
                     const uint32_t c = W.hcnt[h], mc = W.hminc[h];
