@@ -121,7 +121,12 @@ struct DevSeqs {
     int32_t base;           // word / k-mer radix: 21 (protein) or 4 (nucleotide)
     int32_t kd;             // k-mer length of the diagonal test: 2 or 4
     int32_t nt;             // nucleotide rules
+    // an index entry = sequence index in the low `mshift` bits | min(multiplicity of the word in that sequence,
+    // field maximum) above them; the field maximum itself means "look it up in the word list"
+    uint32_t mshift;
 };
+__device__ __forceinline__ uint32_t entry_rmask(const DevSeqs &S) { return (1u << S.mshift) - 1u; }
+__device__ __forceinline__ uint32_t entry_fmax(const DevSeqs &S) { return 0xFFFFFFFFu >> S.mshift; }
 __device__ __forceinline__ uint32_t real_of(const DevSeqs &S, uint32_t k) { return k >= S.n_fwd ? k - S.n_fwd : k; }
 
 // ----------------------------------------------------------------------------------------
@@ -361,7 +366,6 @@ struct __attribute__((aligned(64))) IndexLine {
     uint32_t e[kInline];
 };
 static_assert(sizeof(IndexLine) == 64, "one line per word code");
-constexpr uint32_t kMultiBit = 0x80000000u;
 
 // Appending the representatives list[*d_lo .. *d_hi): three passes over their word lists.
 // (1) count the new entries per code, remembering the codes touched for the first time
@@ -429,7 +433,8 @@ __global__ __launch_bounds__(256) void index_write_kernel(DevSeqs S, const uint3
             const uint32_t code = S.wcode[o + i];
             IndexLine &L = lines[code];
             const uint32_t pos = atomicAdd(&L.len, 1u);
-            const uint32_t entry = k | (S.wmult[o + i] > 1 ? kMultiBit : 0u);
+            const uint32_t m = S.wmult[o + i], fmax = entry_fmax(S);
+            const uint32_t entry = k | ((m < fmax ? m : fmax) << S.mshift);
             if (pos < kInline) L.e[pos] = entry;
             else pool[L.ovf + 1u + (pos - kInline)] = entry;
         }
@@ -531,22 +536,25 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
                                             uint64_t o, uint32_t nw, uint32_t q, uint32_t thr, bool count_only,
                                             uint32_t class_k, uint32_t class_j, uint32_t &visits, bool &hot,
                                             bool &full) {
+    const uint32_t rmask = entry_rmask(S), fmax = entry_fmax(S);
     auto entry_visit = [&](uint32_t entry, uint32_t code, uint32_t mq) {
-        const uint32_t r = entry & ~kMultiBit;
+        const uint32_t r = entry & rmask;
         if (r >= q) return;                      // only representatives created before the query
         uint32_t c = 1u;
-        if (mq > 1u && (entry & kMultiBit)) {
-            const uint32_t mr = word_mult_of(S.wcode, S.wmult, S.off[r], S.wcnt[r], code);
+        if (mq > 1u) {
+            uint32_t mr = entry >> S.mshift;
+            if (mr == fmax) mr = word_mult_of(S.wcode, S.wmult, S.off[r], S.wcnt[r], code);
             c = mr < mq ? mr : mq;
         }
         const uint32_t b = (r * 0x9E3779B1u) >> 22;   // 10 bits
         if (!PASS2) {
             ++visits;
             if (count_only) return;
+            if (thr == 1u) { hot = true; return; }    // one shared word makes a candidate: nothing to bound
             const uint32_t old = atomicAdd(&W.bucket[b], c);
             hot |= old + c >= thr;
         } else {
-            if (W.bucket[b] < thr) return;
+            if (thr > 1u && W.bucket[b] < thr) return;
             if (((((r ^ (r >> 15)) * 0x85EBCA6Bu) >> 9) & (class_k - 1u)) != class_j) return;
             const uint32_t h = exact_slot<FH>(W.hrep, r);
             if (h == (uint32_t)FH) { full = true; return; }
@@ -569,7 +577,11 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
         const uint32_t hi = la.x;
         const uint32_t lo = NEWONLY ? (la.w == A.epoch ? la.z : hi) : 0u;
         const uint32_t hi_in = hi < kInline ? hi : kInline;
-        for (uint32_t j = lo; j < hi_in; ++j) {
+        // the lanes start at different entries of their lines: lists keep insertion order, so in a family (or with
+        // few codes) entry j of every lane's list is the same representative -- 64 atomics on one LDS address
+        const uint32_t n_in = hi_in > lo ? hi_in - lo : 0u;
+        uint32_t j = lo + ((lane * n_in) >> 6);
+        for (uint32_t t = 0; t < n_in; ++t, j = j + 1u == hi_in ? lo : j + 1u) {
             uint32_t e = lb.y;                     // entry j, picked from the line's registers
             e = j == 1 ? lb.z : e; e = j == 2 ? lb.w : e; e = j == 3 ? lc.x : e; e = j == 4 ? lc.y : e;
             e = j == 5 ? lc.z : e; e = j == 6 ? lc.w : e; e = j == 7 ? ld.x : e; e = j == 8 ? ld.y : e;
@@ -694,10 +706,9 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
 // others; once the block is decided, the entries of the members that joined a representative are
 // struck out again (overwritten by an index no query precedes). One wave per member; the entries sit
 // in the part of their lists the round added.
-constexpr uint32_t kTombstone = 0x7FFFFFFFu;
 __global__ __launch_bounds__(256) void index_strike_kernel(DevSeqs S, const uint32_t *__restrict__ list, uint32_t n,
                                                           IndexLine *__restrict__ lines, uint32_t *__restrict__ pool) {
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, rmask = entry_rmask(S);   // tombstone = rmask: an index no query precedes
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
         const uint32_t k = list[w];
         const uint64_t o = S.off[k];
@@ -707,7 +718,7 @@ __global__ __launch_bounds__(256) void index_strike_kernel(DevSeqs S, const uint
             const uint32_t hi = L.len;
             for (uint32_t j = L.len_prev; j < hi; ++j) {
                 uint32_t *e = j < kInline ? &L.e[j] : &pool[L.ovf + 1u + (j - kInline)];
-                if ((*e & ~kMultiBit) == k) { *e = kTombstone; break; }
+                if ((*e & rmask) == k) { *e = rmask; break; }
             }
         }
     }
@@ -1733,7 +1744,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     for (uint32_t i = 0; i < n_in; ++i)
         if ((int)in_len[i] > P->min_length) order[bucket[max_len - in_len[i]]++] = i;
     if (n == 0) { if (stats) *stats = S; return PGX_OK; }
-    PGX_REQUIRE(n < 0x7FFFFFF0u, "too many sequences for 31-bit index entries");
+    PGX_REQUIRE(n < (1u << 30), "too many sequences for the index entries (30 bits)");
+    uint32_t mshift = 8;                         // smallest field that holds n (and the strike-out value above it)
+    while ((1u << mshift) <= n) ++mshift;
 
     // sequences n .. 2n-1 are the reverse complements (nucleotides, both strands)
     const uint32_t nv = both ? 2 * n : n;
@@ -1931,7 +1944,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     }
     DevSeqs DS{d_res.as<uint8_t>(), d_off.as<uint64_t>(), d_len.as<uint32_t>(),
                d_wcode.as<uint32_t>(), d_wmult.as<uint16_t>(), d_wcnt.as<uint32_t>(),
-               d_pk.as<uint32_t>(), d_pkoff.as<uint32_t>(), n, nt ? 4 : kNAA1, nt ? 4 : 2, nt ? 1 : 0};
+               d_pk.as<uint32_t>(), d_pkoff.as<uint32_t>(), n, nt ? 4 : kNAA1, nt ? 4 : 2, nt ? 1 : 0, mshift};
     HostVec<uint32_t> h_wcnt(ctx, 8, n);
     PGX_REQUIRE(h_wcnt.ok(), "out of host memory");
     PGX_HIP(hipMemcpyAsync(h_wcnt.data(), d_wcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
