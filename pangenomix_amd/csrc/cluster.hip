@@ -562,12 +562,25 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             atomicMin(&W.hminc[h], code);
         }
     };
-    for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+    // The word loads run two slabs ahead of the slab being processed and the bit-map probes one slab ahead, so
+    // that a slab costs one memory round trip (its lines) instead of three dependent ones (a multiplicity of 0
+    // marks a lane without a word).
+    auto load_word = [&](uint32_t w0, uint32_t &c, uint32_t &m) {
         const uint32_t w = w0 + lane;
-        bool live = w < nw;
-        const uint32_t code = live ? S.wcode[o + w] : 0u;
-        const uint32_t mq = live ? S.wmult[o + w] : 0u;
-        if (NEWONLY && live) live = (A.newbits[code >> 5] >> (code & 31u)) & 1u;
+        c = 0u; m = 0u;
+        if (w < nw) { c = S.wcode[o + w]; m = S.wmult[o + w]; }
+    };
+    uint32_t c1, m1, c2, m2, nb1 = ~0u;
+    load_word(0u, c1, m1);
+    load_word(64u, c2, m2);
+    if (NEWONLY && m1) nb1 = A.newbits[c1 >> 5];
+    for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+        const uint32_t code = c1, mq = m1;
+        const bool live = mq != 0u && ((nb1 >> (code & 31u)) & 1u);
+        c1 = c2; m1 = m2;
+        load_word(w0 + 128u, c2, m2);
+        nb1 = ~0u;
+        if (NEWONLY && m1) nb1 = A.newbits[c1 >> 5];
         uint4 la = make_uint4(0u, 0u, 0u, 0u), lb = la, lc = la, ld = la;
         if (live) {
             const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + code);
@@ -620,8 +633,11 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     __shared__ uint4 s_lq[4][64];
     __shared__ uint32_t s_pref[4][64];
     __shared__ uint2 s_work[4][kFWork];
+    __shared__ unsigned long long s_visits;
     if (NEWONLY && *A.d_round_lo >= *A.d_round_hi) return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    if (threadIdx.x == 0) s_visits = 0ull;
+    __syncthreads();
     const FilterWave W{s_bucket[wave], s_hrep[wave], s_hcnt[wave], s_hminc[wave], s_lq[wave], s_pref[wave]};
     uint2 *work = s_work[wave];
     for (uint32_t i = lane; i < kFB; i += 64) W.bucket[i] = 0u;
@@ -630,6 +646,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
 
     const uint32_t n_list = A.qlist ? *A.d_nq : 0u;
     const uint32_t n_slots = A.qlist ? (A.ns > A.nbq ? 2u * n_list : n_list) : A.ns;
+    unsigned long long wave_visits = 0ull;   // lane 0: posting visits of this wave's members
     for (uint32_t s = blockIdx.x * 4 + wave; s < n_slots; s += gridDim.x * 4) {
         // window slot -> member, strand (block mode: slots enumerate the block list, then its reverse strands)
         const uint32_t half = A.qlist ? n_list : A.nbq;
@@ -650,7 +667,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         for (int d = 32; d > 0; d >>= 1) visits += __shfl_xor(visits, d);
         if (visits && lane == 0 && A.count_visits) {
             if (NT && rstrand) atomicAdd(&A.rc_visits[ql], (unsigned long long)visits);
-            else atomicAdd(A.visits, (unsigned long long)visits);
+            else wave_visits += visits;     // (one global atomic per member on ONE address was the floor of a pass)
         }
         if (__ballot(hot)) {
             // exact pass per residue class of the hot representatives, refined while the table overflows
@@ -699,6 +716,9 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
             wave_lds_sync();
         }
     }
+    if (lane == 0 && wave_visits) atomicAdd(&s_visits, wave_visits);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_visits) atomicAdd(A.visits, s_visits);
 }
 
 // Tentative entries: a block's members are appended to the index as if all of them were
