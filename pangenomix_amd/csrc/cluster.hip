@@ -634,6 +634,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     __shared__ uint32_t s_pref[4][64];
     __shared__ uint2 s_work[4][kFWork];
     __shared__ unsigned long long s_visits;
+    __shared__ uint4 s_stage[4][64];
     if (NEWONLY && *A.d_round_lo >= *A.d_round_hi) return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (threadIdx.x == 0) s_visits = 0ull;
@@ -647,6 +648,24 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     const uint32_t n_list = A.qlist ? *A.d_nq : 0u;
     const uint32_t n_slots = A.qlist ? (A.ns > A.nbq ? 2u * n_list : n_list) : A.ns;
     unsigned long long wave_visits = 0ull;   // lane 0: posting visits of this wave's members
+    uint4 *stage = s_stage[wave];
+    uint32_t n_stage = 0;                    // staged pair records of this wave (wave-uniform)
+    auto flush_pairs = [&]() {
+        if (n_stage == 0u) return;
+        wave_lds_sync();
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(A.n_pairs, n_stage);
+        base = __shfl(base, 0);
+        if (lane < n_stage && base + lane < A.pair_cap) {
+            const uint4 v = stage[lane];
+            Pair p;
+            p.q = v.x; p.r = v.y; p.cnt = v.z; p.minc = v.w;
+            p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
+            A.pairs[base + lane] = p;
+        }
+        __builtin_amdgcn_wave_barrier();
+        n_stage = 0u;
+    };
     for (uint32_t s = blockIdx.x * 4 + wave; s < n_slots; s += gridDim.x * 4) {
         // window slot -> member, strand (block mode: slots enumerate the block list, then its reverse strands)
         const uint32_t half = A.qlist ? n_list : A.nbq;
@@ -690,23 +709,29 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
                 }
                 for (uint32_t h = lane; h < (uint32_t)FH; h += 64) {
                     const uint32_t r = W.hrep[h];
-                    if (r == kEmpty) continue;
-                    const uint32_t c = W.hcnt[h], mc = W.hminc[h];
-                    W.hrep[h] = kEmpty; W.hcnt[h] = 0u; W.hminc[h] = kSentinel;
-                    if (over || c < thr) continue;
-                    const unsigned long long key = ((unsigned long long)rstrand << 63) | ((unsigned long long)mc << 32) | r;
-                    if (NEWONLY) {   // only candidates whose key can still beat the member's current best
+                    bool emit = r != kEmpty;
+                    uint32_t c = 0u, mc = 0u;
+                    if (emit) {
+                        c = W.hcnt[h]; mc = W.hminc[h];
+                        W.hrep[h] = kEmpty; W.hcnt[h] = 0u; W.hminc[h] = kSentinel;
+                        emit = !over && c >= thr;
+                    }
+                    if (NEWONLY && emit) {   // only candidates whose key can still beat the member's current best
+                        const unsigned long long key = ((unsigned long long)rstrand << 63) | ((unsigned long long)mc << 32) | r;
                         const unsigned long long bo = A.best[ql];
-                        if (bo != kNoBest && key > bo) continue;
+                        emit = bo == kNoBest || key <= bo;
                     }
-                    if (A.mark) A.mark[ql] = 1;
-                    const uint32_t slot = atomicAdd(A.n_pairs, 1u);
-                    if (slot < A.pair_cap) {
-                        Pair p;
-                        p.q = k; p.r = r; p.cnt = c; p.minc = mc;
-                        p.best_sum = 0; p.band_left = p.band_center = p.band_right = 0; p.iden = 0; p.flags = 0;
-                        A.pairs[slot] = p;
+                    // pair records are staged per wave and go out 64 at a time (one atomic on the pair counter
+                    // per batch, not per member)
+                    const unsigned long long em = __ballot(emit);
+                    if (!em) continue;
+                    const uint32_t n_em = (uint32_t)__popcll(em);
+                    if (n_stage + n_em > 64u) flush_pairs();
+                    if (emit) {
+                        if (A.mark) A.mark[ql] = 1;
+                        stage[n_stage + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = make_uint4(k, r, c, mc);
                     }
+                    n_stage += n_em;
                 }
                 wave_lds_sync();
             }
@@ -716,6 +741,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
             wave_lds_sync();
         }
     }
+    flush_pairs();
     if (lane == 0 && wave_visits) atomicAdd(&s_visits, wave_visits);
     __syncthreads();
     if (threadIdx.x == 0 && s_visits) atomicAdd(A.visits, s_visits);
