@@ -531,12 +531,35 @@ __device__ __forceinline__ uint32_t exact_slot(uint32_t *hrep, uint32_t r) {
 // One walk over the words [0, nw) at `o` of a query strand. PASS2 = false: count into the buckets
 // (`visits`, `hot`); true: accumulate the representatives of hot buckets whose residue class is
 // (class_k, class_j) in the exact table (`full` when it overflows).
+// Development aid (make EXTRA=-DPGX_FTIME): shader-clock time per section of the filter kernel, summed over waves.
+#ifdef PGX_FTIME
+__device__ unsigned long long g_ftime[16];
+struct FTimer {
+    unsigned long long t, acc[12];
+    __device__ void start() { t = clock64(); }
+    __device__ void lap(int i) { const unsigned long long n = clock64(); acc[i] += n - t; t = n; }
+};
+#define FT_LAP(ft, i) (ft).lap(i)
+#else
+struct FTimer { __device__ void start() {} };
+#define FT_LAP(ft, i) ((void)0)
+#endif
+
+// NEWONLY: the query's words whose code the round touched, compacted (one per lane); `complete` when these are all
+// of them, so that the exact pass need not walk the word list again
+struct Marked { uint32_t code, mult, n; bool complete; };
+
 template <bool NEWONLY, bool PASS2, int FH>
 __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &A, const FilterWave &W, uint32_t lane,
                                             uint64_t o, uint32_t nw, uint32_t q, uint32_t thr, bool count_only,
                                             uint32_t class_k, uint32_t class_j, uint32_t &visits, bool &hot,
-                                            bool &full) {
+                                            bool &full, Marked &M, FTimer &ft, bool redo = false) {
     const uint32_t rmask = entry_rmask(S), fmax = entry_fmax(S);
+    // NEWONLY, first walk: when all the marked words fit one slab (the usual case: a round adds few entries to a
+    // query's lists), the representatives met go straight into the exact table -- no bucket pass, no second walk.
+    // If the table overflows, the walk is redone (`redo`) on the marked words with the buckets, visits not counted
+    // again, and the exact passes per residue class follow as for any other walk.
+    bool direct = false;
     auto entry_visit = [&](uint32_t entry, uint32_t code, uint32_t mq) {
         const uint32_t r = entry & rmask;
         if (r >= q) return;                      // only representatives created before the query
@@ -548,8 +571,15 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
         }
         const uint32_t b = (r * 0x9E3779B1u) >> 22;   // 10 bits
         if (!PASS2) {
-            ++visits;
+            if (!redo) ++visits;
             if (count_only) return;
+            if (direct) {
+                const uint32_t h = exact_slot<FH>(W.hrep, r);
+                if (h == (uint32_t)FH) { full = true; return; }
+                atomicAdd(&W.hcnt[h], c);
+                atomicMin(&W.hminc[h], code);
+                return;
+            }
             if (thr == 1u) { hot = true; return; }    // one shared word makes a candidate: nothing to bound
             const uint32_t old = atomicAdd(&W.bucket[b], c);
             hot |= old + c >= thr;
@@ -562,25 +592,8 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             atomicMin(&W.hminc[h], code);
         }
     };
-    // The word loads run two slabs ahead of the slab being processed and the bit-map probes one slab ahead, so
-    // that a slab costs one memory round trip (its lines) instead of three dependent ones (a multiplicity of 0
-    // marks a lane without a word).
-    auto load_word = [&](uint32_t w0, uint32_t &c, uint32_t &m) {
-        const uint32_t w = w0 + lane;
-        c = 0u; m = 0u;
-        if (w < nw) { c = S.wcode[o + w]; m = S.wmult[o + w]; }
-    };
-    uint32_t c1, m1, c2, m2, nb1 = ~0u;
-    load_word(0u, c1, m1);
-    load_word(64u, c2, m2);
-    if (NEWONLY && m1) nb1 = A.newbits[c1 >> 5];
-    for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
-        const uint32_t code = c1, mq = m1;
-        const bool live = mq != 0u && ((nb1 >> (code & 31u)) & 1u);
-        c1 = c2; m1 = m2;
-        load_word(w0 + 128u, c2, m2);
-        nb1 = ~0u;
-        if (NEWONLY && m1) nb1 = A.newbits[c1 >> 5];
+    // One slab: up to 64 words (one per lane), their lines, the entries.
+    auto slab = [&](uint32_t code, uint32_t mq, bool live) {
         uint4 la = make_uint4(0u, 0u, 0u, 0u), lb = la, lc = la, ld = la;
         if (live) {
             const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + code);
@@ -622,7 +635,66 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             }
             __builtin_amdgcn_wave_barrier();
         }
+    };
+    auto load_word = [&](uint32_t w0, uint32_t &c, uint32_t &m) {   // (a multiplicity of 0 marks a lane without a word)
+        const uint32_t w = w0 + lane;
+        c = 0u; m = 0u;
+        if (w < nw) { c = S.wcode[o + w]; m = S.wmult[o + w]; }
+    };
+    if (!NEWONLY) {
+        // every word has a list to walk: the word loads run one slab ahead of the slab being processed
+        uint32_t c1, m1;
+        load_word(0u, c1, m1);
+        for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+            const uint32_t code = c1, mq = m1;
+            load_word(w0 + 64u, c1, m1);
+            slab(code, mq, mq != 0u);
+        }
+        return;
     }
+    // NEWONLY: only the words whose code the round touched (its bit map) have anything to visit -- a few per
+    // slab. The waves of this kernel wait for memory nearly all of their time with about one load in flight, so
+    // the loads of up to 512 words and then all their bit-map probes are issued together, the marked words are
+    // compacted across the slabs in registers (a rotation of the lanes by ds_permute: a slab's marked words go
+    // behind the `np` words already pending, the others behind those), and a slab of lines is only walked once
+    // 64 marked words are together, and for what is left at the end.
+    if ((PASS2 || redo) && M.complete) { slab(M.code, M.mult, lane < M.n); FT_LAP(ft, 6); return; }
+    uint32_t pc = 0u, pm = 0u, np = 0u;
+    bool flushed = false;
+    for (uint32_t base = 0; base < nw; base += 512u) {
+        uint32_t c[8], m[8], nbw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load_word(base + 64u * j, c[j], m[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { nbw[j] = 0u; if (m[j]) nbw[j] = A.newbits[c[j] >> 5]; }
+        if (!PASS2) { if (__ballot(nbw[0] == 0x12345u && nbw[7] == 0x54321u) == ~0ull) return; FT_LAP(ft, 1); }   // (waits for the probes)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (base + 64u * j >= nw) break;
+            const bool live = (nbw[j] >> (c[j] & 31u)) & 1u;
+            const unsigned long long mask = __ballot(live);
+            if (!mask) continue;
+            const uint32_t n = (uint32_t)__popcll(mask);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            const uint32_t tgt = live ? np + below : np + n + (lane - below);       // a bijection of the lanes (mod 64)
+            const uint32_t xc = (uint32_t)__builtin_amdgcn_ds_permute((int)(tgt << 2), (int)c[j]);
+            const uint32_t xm = (uint32_t)__builtin_amdgcn_ds_permute((int)(tgt << 2), (int)(live ? m[j] : 0u));
+            if (np + n >= 64u) {      // lanes [np, 64) complete the pending slab; lanes [0, np + n - 64) hold the rest
+                slab(lane >= np ? xc : pc, lane >= np ? xm : pm, true);
+                flushed = true;
+                np = np + n - 64u;
+                pc = xc; pm = lane < np ? xm : 0u;
+            } else {
+                if (lane >= np && lane < np + n) { pc = xc; pm = xm; }
+                np += n;
+            }
+        }
+    }
+    if (!PASS2) FT_LAP(ft, 2);
+    direct = !PASS2 && !flushed;
+    if (np) slab(pc, pm, lane < np);
+    if (!PASS2) { M.code = pc; M.mult = pm; M.n = np; M.complete = !flushed; FT_LAP(ft, 3); }
+    else FT_LAP(ft, 6);
 }
 
 template <bool NT, bool NEWONLY>
@@ -666,6 +738,8 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         __builtin_amdgcn_wave_barrier();
         n_stage = 0u;
     };
+    FTimer ft{};
+    ft.start();
     for (uint32_t s = blockIdx.x * 4 + wave; s < n_slots; s += gridDim.x * 4) {
         // window slot -> member, strand (block mode: slots enumerate the block list, then its reverse strands)
         const uint32_t half = A.qlist ? n_list : A.nbq;
@@ -681,14 +755,69 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         const uint32_t nw = S.wcnt[k];
         uint32_t visits = 0;
         bool hot = false, full = false;
-        filter_walk<NEWONLY, false, FH>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full);
+        Marked marked{0u, 0u, 0u, false};
+        if (__ballot(nw == 0xFFFFFFFFu && thr == 0u) == ~0ull) return;   // (consumes the prologue loads)
+        FT_LAP(ft, 0);
+        filter_walk<NEWONLY, false, FH>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full, marked, ft);
         wave_lds_sync();
         for (int d = 32; d > 0; d >>= 1) visits += __shfl_xor(visits, d);
+        FT_LAP(ft, 4);
         if (visits && lane == 0 && A.count_visits) {
             if (NT && rstrand) atomicAdd(&A.rc_visits[ql], (unsigned long long)visits);
             else wave_visits += visits;     // (one global atomic per member on ONE address was the floor of a pass)
         }
-        if (__ballot(hot)) {
+        // the exact table -> pair records (staged per wave, 64 at a time: one atomic on the pair counter per
+        // batch, not per member); `over`: the table overflowed, its content is dropped
+        auto emit_table = [&](bool over) {
+            for (uint32_t h = lane; h < (uint32_t)FH; h += 64) {
+                const uint32_t r = W.hrep[h];
+                bool emit = r != kEmpty;
+                uint32_t c = 0u, mc = 0u;
+                if (emit) {
+                    c = W.hcnt[h]; mc = W.hminc[h];
+                    W.hrep[h] = kEmpty; W.hcnt[h] = 0u; W.hminc[h] = kSentinel;
+                    emit = !over && c >= thr;
+                }
+                if (NEWONLY && emit) {   // only candidates whose key can still beat the member's current best
+                    const unsigned long long key = ((unsigned long long)rstrand << 63) | ((unsigned long long)mc << 32) | r;
+                    const unsigned long long bo = A.best[ql];
+                    emit = bo == kNoBest || key <= bo;
+                }
+                const unsigned long long em = __ballot(emit);
+                if (!em) continue;
+                const uint32_t n_em = (uint32_t)__popcll(em);
+                if (n_stage + n_em > 64u) flush_pairs();
+                if (emit) {
+                    if (A.mark) A.mark[ql] = 1;
+                    stage[n_stage + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = make_uint4(k, r, c, mc);
+                }
+                n_stage += n_em;
+            }
+            wave_lds_sync();
+        };
+        bool direct_done = NEWONLY && marked.complete && !count_only;   // (wave-uniform)
+        if (direct_done && visits) {
+            if (__ballot(full)) {
+#ifdef PGX_FTIME
+                if (lane == 0) atomicAdd(&g_ftime[14], 1ull);
+#endif
+                emit_table(true);
+                full = false; hot = false;
+                filter_walk<NEWONLY, false, FH>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full, marked, ft, true);
+                wave_lds_sync();
+                direct_done = false;
+            } else {
+                emit_table(false);
+                FT_LAP(ft, 8);
+#ifdef PGX_FTIME
+                if (lane == 0) atomicAdd(&g_ftime[13], 1ull);
+#endif
+            }
+        }
+#ifdef PGX_FTIME
+        if (!direct_done && __ballot(hot) && lane == 0) atomicAdd(&g_ftime[15], 1ull);
+#endif
+        if (!direct_done && __ballot(hot)) {
             // exact pass per residue class of the hot representatives, refined while the table overflows
             uint32_t n_work = 1;
             if (lane == 0) work[0] = make_uint2(1u, 0u);
@@ -697,8 +826,10 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
                 const uint2 cls = work[n_work - 1];
                 --n_work;
                 full = false;
-                filter_walk<NEWONLY, true, FH>(S, A, W, lane, o, nw, q, thr, false, cls.x, cls.y, visits, hot, full);
+                FT_LAP(ft, 5);
+                filter_walk<NEWONLY, true, FH>(S, A, W, lane, o, nw, q, thr, false, cls.x, cls.y, visits, hot, full, marked, ft);
                 wave_lds_sync();
+                FT_LAP(ft, 7);
                 const bool over = __ballot(full) != 0ull;
                 if (over) {
                     if (cls.x >= (1u << 20) || n_work + 4 > (uint32_t)kFWork) { if (lane == 0) *A.err = 3u; n_work = 0; }
@@ -707,41 +838,24 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
                         n_work += 4;
                     }
                 }
-                for (uint32_t h = lane; h < (uint32_t)FH; h += 64) {
-                    const uint32_t r = W.hrep[h];
-                    bool emit = r != kEmpty;
-                    uint32_t c = 0u, mc = 0u;
-                    if (emit) {
-                        c = W.hcnt[h]; mc = W.hminc[h];
-                        W.hrep[h] = kEmpty; W.hcnt[h] = 0u; W.hminc[h] = kSentinel;
-                        emit = !over && c >= thr;
-                    }
-                    if (NEWONLY && emit) {   // only candidates whose key can still beat the member's current best
-                        const unsigned long long key = ((unsigned long long)rstrand << 63) | ((unsigned long long)mc << 32) | r;
-                        const unsigned long long bo = A.best[ql];
-                        emit = bo == kNoBest || key <= bo;
-                    }
-                    // pair records are staged per wave and go out 64 at a time (one atomic on the pair counter
-                    // per batch, not per member)
-                    const unsigned long long em = __ballot(emit);
-                    if (!em) continue;
-                    const uint32_t n_em = (uint32_t)__popcll(em);
-                    if (n_stage + n_em > 64u) flush_pairs();
-                    if (emit) {
-                        if (A.mark) A.mark[ql] = 1;
-                        stage[n_stage + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = make_uint4(k, r, c, mc);
-                    }
-                    n_stage += n_em;
-                }
-                wave_lds_sync();
+                emit_table(over);
+                FT_LAP(ft, 8);
             }
         }
-        if (visits && !count_only) {
+        if (visits && !count_only && !direct_done) {
             for (uint32_t i = lane * 4; i < (uint32_t)kFB; i += 256) *reinterpret_cast<uint4 *>(&W.bucket[i]) = make_uint4(0u, 0u, 0u, 0u);
             wave_lds_sync();
         }
+        FT_LAP(ft, 9);
     }
     flush_pairs();
+#ifdef PGX_FTIME
+    FT_LAP(ft, 10);
+    if (lane == 0 && NEWONLY && !A.qlist) {
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_ftime[i], ft.acc[i]);
+        atomicAdd(&g_ftime[12], 1ull);
+    }
+#endif
     if (lane == 0 && wave_visits) atomicAdd(&s_visits, wave_visits);
     __syncthreads();
     if (threadIdx.x == 0 && s_visits) atomicAdd(A.visits, s_visits);
@@ -2182,7 +2296,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // index, and the pass against them assigns most of the remaining members; a second round confirms
         // the members the first round's representatives rejected (the outliers of their families). All on
         // the device: the host learns the outcome with the first block's results.
-        for (int round = 0; round < kDiscoveryRounds; ++round) {
+        static const int n_disc = std::getenv("PGX_ROUNDS") ? std::atoi(std::getenv("PGX_ROUNDS")) : kDiscoveryRounds;
+        for (int round = 0; round < n_disc; ++round) {
             if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)max_chunks * n_codes * 4, st)); epoch_tag = 1; }
             zero_kernel<<<1024, 256, 0, st>>>(d_chunkbits.as<uint4>(), ((size_t)n_codes + 3) / 4);
             round_begin_kernel<<<1, 1, 0, st>>>(dc);
@@ -2507,6 +2622,19 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count() - g_wait_s -
                        t_resolve - t_close));
 
+#ifdef PGX_FTIME
+    {
+        unsigned long long h[16], z[16] = {0};
+        PGX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ftime), sizeof h));
+        PGX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ftime), z, sizeof z));
+        static const char *nm[12] = {"prologue", "words+probes", "compaction", "last slab", "sync+reduce", "pass2 begin",
+                                     "pass2 walk", "pass2 sync", "emit", "bucket clear", "kernel end", "-"};
+        double tot = 0;
+        for (int i = 0; i < 12; ++i) tot += (double)h[i];
+        for (int i = 0; i < 11; ++i) fprintf(stderr, "[ftime] %-14s %6.2f %%\n", nm[i], 100.0 * (double)h[i] / tot);
+        fprintf(stderr, "[ftime] %llu waves, %.0f clocks per wave; direct %llu, fallbacks %llu, classic %llu\n", h[12], tot / (double)h[12], h[13], h[14], h[15]);
+    }
+#endif
     unsigned long long visits_table = 0;
     PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
