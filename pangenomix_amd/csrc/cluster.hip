@@ -44,6 +44,9 @@
 #include <cmath>
 #include <type_traits>
 #include <functional>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "cluster_tables.h"
@@ -1794,6 +1797,70 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                                uint8_t *out_strand, uint32_t *out_n_clusters,
                                pgx_cluster_stats *stats, void *stream_);
 
+// The per-sequence host loops before and after the window loop (order, offsets, thresholds, outputs) run on a few
+// threads: with a million sequences they were a tenth of the call. fn(t, begin, end) for contiguous shares.
+// A few worker threads, started at the first large call and parked between regions.
+namespace {
+class HostPool {
+public:
+    static HostPool &get() { static HostPool p; return p; }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    // job(t) for t = 0 .. size()-1, t = 0 on the calling thread; returns when all are done
+    void run(const std::function<void(unsigned)> &job) {
+        std::lock_guard<std::mutex> one(run_m_);   // (callers on several threads, e.g. one context each, take turns)
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &job; pending_ = (unsigned)workers_.size(); ++gen_;
+        }
+        cv_.notify_all();
+        job(0u);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    HostPool() {
+        const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        for (unsigned t = 1; t < hw; ++t) workers_.emplace_back([this, t] { loop(t); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto &w : workers_) w.join();
+    }
+    void loop(unsigned t) {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                job = job_;
+            }
+            (*job)(t);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+}  // namespace
+static unsigned host_threads(size_t n) { return n < (1u << 17) ? 1u : HostPool::get().size(); }
+template <class F>
+static void parallel_for(size_t n, unsigned nt, F fn) {
+    if (nt <= 1) { fn(0u, (size_t)0, n); return; }
+    const size_t per = (n + nt - 1) / nt;
+    HostPool::get().run([&](unsigned t) { fn(t, std::min(n, t * per), std::min(n, (t + 1) * per)); });
+}
+
 extern "C" uint32_t pgx_cluster_window_cap(const pgx_cluster_params *P) {
     if (!P) return 0;
     const bool both = P->alphabet == 1 && P->both_strands != 0;
@@ -1865,10 +1932,13 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     pgx_cluster_stats S{};
     S.n_input = n_in;
     if (out_n_clusters) *out_n_clusters = 0;
-    for (uint32_t i = 0; i < n_in; ++i) {
-        out_cluster[i] = -1; out_member[i] = -1; out_identity[i] = 0.f;
-        if (out_strand) out_strand[i] = 0;
-    }
+    const unsigned nth = host_threads(n_in);
+    parallel_for(n_in, nth, [&](unsigned, size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            out_cluster[i] = -1; out_member[i] = -1; out_identity[i] = 0.f;
+            if (out_strand) out_strand[i] = 0;
+        }
+    });
     if (n_in == 0) { if (stats) *stats = S; return PGX_OK; }
 
     // ---- A.2 / A.3: letters -> indices, stable descending-length order ---------------------
@@ -1888,21 +1958,39 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(hipMemcpyAsync(in_len.data(), d_in_len.p, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
     uint32_t max_len = 0;
-    for (uint32_t i = 0; i < n_in; ++i) max_len = std::max(max_len, in_len[i]);
+    {
+        std::vector<uint32_t> mx(nth, 0u);
+        parallel_for(n_in, nth, [&](unsigned t, size_t b, size_t e) {
+            uint32_t m = 0;
+            for (size_t i = b; i < e; ++i) m = std::max(m, in_len[i]);
+            mx[t] = m;
+        });
+        for (uint32_t m : mx) max_len = std::max(max_len, m);
+    }
     if (max_len > (nt ? kMaxLen / 2 : kMaxLen)) {  // (the 4-mer complexity weights need 18 bits beyond 16383)
         pgx_set_error("pgx_cluster_greedy: sequence of %u residues exceeds the supported maximum %u", max_len,
                       nt ? kMaxLen / 2 : kMaxLen);
         return PGX_ERR_CAPACITY;
     }
-    std::vector<uint32_t> bucket((size_t)max_len + 2, 0);
-    for (uint32_t i = 0; i < n_in; ++i)
-        if ((int)in_len[i] > P->min_length) bucket[max_len - in_len[i] + 1]++;
-    for (uint32_t l = 0; l <= max_len; ++l) bucket[l + 1] += bucket[l];
-    const uint32_t n = bucket[max_len + 1];
+    // stable counting sort by descending length: a histogram per thread over its share of the input, then
+    // every thread places its share behind the shares before it
+    const size_t n_bkt = (size_t)max_len + 2;
+    std::vector<uint32_t> bucket(n_bkt * nth, 0);   // [t][l]
+    parallel_for(n_in, nth, [&](unsigned t, size_t b, size_t e) {
+        uint32_t *h = bucket.data() + n_bkt * t;
+        for (size_t i = b; i < e; ++i)
+            if ((int)in_len[i] > P->min_length) h[max_len - in_len[i]]++;
+    });
+    uint32_t n = 0;
+    for (size_t l = 0; l < n_bkt; ++l)
+        for (unsigned t = 0; t < nth; ++t) { const uint32_t c = bucket[n_bkt * t + l]; bucket[n_bkt * t + l] = n; n += c; }
     HostVec<uint32_t> order(ctx, 1, n);
     PGX_REQUIRE(order.ok(), "out of host memory");
-    for (uint32_t i = 0; i < n_in; ++i)
-        if ((int)in_len[i] > P->min_length) order[bucket[max_len - in_len[i]]++] = i;
+    parallel_for(n_in, nth, [&](unsigned t, size_t b, size_t e) {
+        uint32_t *h = bucket.data() + n_bkt * t;
+        for (size_t i = b; i < e; ++i)
+            if ((int)in_len[i] > P->min_length) order[h[max_len - in_len[i]]++] = (uint32_t)i;
+    });
     if (n == 0) { if (stats) *stats = S; return PGX_OK; }
     PGX_REQUIRE(n < (1u << 30), "too many sequences for the index entries (30 bits)");
     uint32_t mshift = 8;                         // smallest field that holds n (and the strike-out value above it)
@@ -1913,34 +2001,52 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     HostVec<uint64_t> h_off(ctx, 2, (size_t)nv + 1);
     HostVec<uint32_t> h_len(ctx, 3, nv);
     PGX_REQUIRE(h_off.ok() && h_len.ok(), "out of host memory");
-    h_off[0] = 0;
-    for (uint32_t k = 0; k < nv; ++k) { h_len[k] = in_len[order[k < n ? k : k - n]]; h_off[k + 1] = h_off[k] + h_len[k]; }
-    const uint64_t total = h_off[nv];
     HostVec<uint32_t> h_pkoff(ctx, 4, (size_t)nv + 1);
     PGX_REQUIRE(h_pkoff.ok(), "out of host memory");
-    h_pkoff[0] = 0;
-    for (uint32_t k = 0; k < nv; ++k) {
-        const uint64_t nxt = (uint64_t)h_pkoff[k] + (h_len[k] + 5) / 6;
-        if (nxt > 0xFFFFFFF0ull) { pgx_set_error("pgx_cluster_greedy: too many residues for 32-bit packed offsets"); return PGX_ERR_CAPACITY; }
-        h_pkoff[k + 1] = (uint32_t)nxt;
-    }
+    // lengths in sorted order; residue and packed-word offsets = prefix sums (per-share sums first, then the shares)
+    std::vector<uint64_t> sum_len(nth + 1, 0), sum_pk(nth + 1, 0);
+    parallel_for(nv, nth, [&](unsigned t, size_t b, size_t e) {
+        uint64_t sl = 0, sp = 0;
+        for (size_t k = b; k < e; ++k) {
+            const uint32_t L = in_len[order[k < n ? k : k - n]];
+            h_len[k] = L; sl += L; sp += (L + 5) / 6;
+        }
+        sum_len[t + 1] = sl; sum_pk[t + 1] = sp;
+    });
+    for (unsigned t = 0; t < nth; ++t) { sum_len[t + 1] += sum_len[t]; sum_pk[t + 1] += sum_pk[t]; }
+    const uint64_t total = sum_len[nth];
+    if (sum_pk[nth] > 0xFFFFFFF0ull) { pgx_set_error("pgx_cluster_greedy: too many residues for 32-bit packed offsets"); return PGX_ERR_CAPACITY; }
+    h_off[0] = 0; h_pkoff[0] = 0;
+    parallel_for(nv, nth, [&](unsigned t, size_t b, size_t e) {
+        uint64_t so = sum_len[t], sp = sum_pk[t];
+        for (size_t k = b; k < e; ++k) {
+            so += h_len[k]; sp += (h_len[k] + 5) / 6;
+            h_off[k + 1] = so; h_pkoff[k + 1] = (uint32_t)sp;
+        }
+    });
     phase("lengths + order");
     // per-query thresholds in double, exactly as the sequential rule computes them
     HostVec<int32_t> h_aa1(ctx, 5, n), h_aas(ctx, 6, n), h_aan(ctx, 7, n);
     PGX_REQUIRE(h_aa1.ok() && h_aas.ok() && h_aan.ok(), "out of host memory");
-    for (uint32_t k = 0; k < n; ++k) {
-        const int len = (int)h_len[k];
-        const int aa1 = (int)(P->identity * (double)len);
-        h_aa1[k] = aa1;
-        if (P->identity > 0.95) {
-            h_aas[k] = len - (nt ? 4 : 2) + 1 - (len - aa1) * (nt ? 4 : 2);
-            h_aan[k] = len - P->word_len + 1 - (len - aa1) * P->word_len;
-        } else {
-            h_aas[k] = (int)(P->aas_cutoff * (double)len);
-            h_aan[k] = (int)(P->aan_cutoff * (double)len);
-        }
-        S.sum_len_queries += (uint64_t)len;
-        PGX_REQUIRE(h_aas[k] >= 1, "aas_cutoff too small: every sequence needs required_aas >= 1");
+    {
+        std::vector<uint8_t> bad(nth, 0);
+        parallel_for(n, nth, [&](unsigned t, size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                const int len = (int)h_len[k];
+                const int aa1 = (int)(P->identity * (double)len);
+                h_aa1[k] = aa1;
+                if (P->identity > 0.95) {
+                    h_aas[k] = len - (nt ? 4 : 2) + 1 - (len - aa1) * (nt ? 4 : 2);
+                    h_aan[k] = len - P->word_len + 1 - (len - aa1) * P->word_len;
+                } else {
+                    h_aas[k] = (int)(P->aas_cutoff * (double)len);
+                    h_aan[k] = (int)(P->aan_cutoff * (double)len);
+                }
+                if (h_aas[k] < 1) bad[t] = 1;
+            }
+        });
+        for (uint8_t b : bad) PGX_REQUIRE(!b, "aas_cutoff too small: every sequence needs required_aas >= 1");
+        S.sum_len_queries = h_off[n];
     }
     S.n_clustered = n;
 
@@ -2646,14 +2752,18 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     phase("window loop");
     // ---- outputs in the caller's order; member numbers follow the sorted order (A.3) ------
     std::vector<uint32_t> members(rep_seq.size(), 0);
-    for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t o = order[k];
-        const int32_t c = cluster_of[k];
-        out_cluster[o] = c;
-        out_member[o] = (int32_t)members[c]++;
-        out_identity[o] = iden_of[k] >= 0 ? (float)iden_of[k] / (float)h_len[k] : 0.f;
-        if (out_strand) out_strand[o] = strand_of[k];   // (set for members only)
-    }
+    HostVec<uint32_t> member_no(ctx, 12, n);
+    PGX_REQUIRE(member_no.ok(), "out of host memory");
+    for (uint32_t k = 0; k < n; ++k) member_no[k] = members[cluster_of[k]]++;   // (in sorted order)
+    parallel_for(n, nth, [&](unsigned, size_t b, size_t e) {
+        for (size_t k = b; k < e; ++k) {
+            const uint32_t o = order[k];
+            out_cluster[o] = cluster_of[k];
+            out_member[o] = (int32_t)member_no[k];
+            out_identity[o] = iden_of[k] >= 0 ? (float)iden_of[k] / (float)h_len[k] : 0.f;
+            if (out_strand) out_strand[o] = strand_of[k];   // (set for members only)
+        }
+    });
     phase("outputs");
     if (out_n_clusters) *out_n_clusters = (uint32_t)rep_seq.size();
     if (stats) *stats = S;
