@@ -2276,13 +2276,15 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     uint64_t n_blocks = 0;
     g_wait_s = 0.0;
     std::function<int()> deferred;  // bookkeeping of the window before, see the close of a window
+    uint64_t pending_words = 0;     // ... and its words
     Chunks chunks;
     for (uint32_t b0 = 0, nb; b0 < n; b0 += nb) {
         nb = form_window(b0, chunks);                      // queries of this window
         const uint32_t ns = both ? 2 * nb : nb;            // window slots: + one per reverse complement
         const uint32_t n_reps = (uint32_t)rep_seq.size();
         const uint64_t window_words = h_off[b0 + nb] - h_off[b0];
-        { int rc = ensure_pool(S.rep_words + window_words); if (rc) return rc; }
+        // (the bookkeeping of the window before may still be pending: its members count as representatives)
+        { int rc = ensure_pool(S.rep_words + pending_words + window_words); if (rc) return rc; }
         uint32_t *d_poolp = d_pool[pool_cur].as<uint32_t>();
         if (nt) {  // at cd-hit-est's -n 5 -c 0.8 one shared word is enough: size the pair buffer for all pairs
             const uint64_t need = (uint64_t)ns * ((uint64_t)n_reps + nb) + 1024;
@@ -2358,7 +2360,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             return exchange_best();
         };
         // phase A: against the representatives that exist already
-        if (n_reps) {
+        if (b0 > 0) {
             {
                 ProfScope prof(ctx, "filter_kernel<all>", st);
                 auto kern = nt ? filter_kernel<true, false> : filter_kernel<false, false>;
@@ -2659,34 +2661,37 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             PGX_HIP(hipMemcpyAsync(hW.p, pairsW, (size_t)nW * sizeof(Pair), hipMemcpyDeviceToHost, st));
             PGX_HIP(spin_sync(st));
         }
-        // members that were never in a block: their winner is the 64-bit minimum in best[]
+        // The window's bookkeeping -- winners, numbering of the new representatives, identities, the candidates
+        // the one-by-one pass would have examined -- works on the host copies only: it is deferred until the
+        // next window's first kernels are enqueued (the device starts the next window right away).
         const auto t_c0 = std::chrono::steady_clock::now();
-        for (uint32_t q = 0; q < nb; ++q) {
-            if (status[q] != ST_OPEN) continue;
-            const unsigned long long key = h_best.p[q];
-            if (key == kNoBest) { pgx_set_error("pgx_cluster_greedy: unresolved member after the last block"); return PGX_ERR_INTERNAL; }
-            status[q] = ST_MEMBER;
-            winner_key[q] = key;
-            strand_of[b0 + q] = (uint8_t)(key >> 63);
-        }
-        if (both)  // reverse-strand word walks happen only for queries the forward strand did not place
-            for (uint32_t q = 0; q < nb; ++q)
-                if (status[q] == ST_REP || (winner_key[q] >> 63)) visits_rc += h_rcvis.p[q];
-        // new representatives are numbered in sequence order
-        for (uint32_t q = 0; q < nb; ++q)
-            if (status[q] == ST_REP) {
-                cluster_of[b0 + q] = (int32_t)rep_seq.size();
-                rep_seq.push_back(b0 + q);
-                S.sum_len_reps += h_len[b0 + q];
-                S.rep_words += h_wcnt[b0 + q];
-            }
-        for (uint32_t q = 0; q < nb; ++q)
-            if (status[q] == ST_MEMBER) cluster_of[b0 + q] = cluster_of[(uint32_t)winner_key[q] & 0x7FFFFFFFu];
-        // identities of the winners + the candidates the one-by-one pass would have examined: pure
-        // bookkeeping on the host copies, deferred until the next window's first kernels are enqueued
         {
             const Pair *pW = hW.p;
-            deferred = [&, b0, nW, pW]() -> int {
+            pending_words = window_words;
+            deferred = [&, b0, nb, nW, pW]() -> int {
+                pending_words = 0;
+                // members that were never in a block: their winner is the 64-bit minimum in best[]
+                for (uint32_t q = 0; q < nb; ++q) {
+                    if (status[q] != ST_OPEN) continue;
+                    const unsigned long long key = h_best.p[q];
+                    if (key == kNoBest) { pgx_set_error("pgx_cluster_greedy: unresolved member after the last block"); return PGX_ERR_INTERNAL; }
+                    status[q] = ST_MEMBER;
+                    winner_key[q] = key;
+                    strand_of[b0 + q] = (uint8_t)(key >> 63);
+                }
+                if (both)  // reverse-strand word walks happen only for queries the forward strand did not place
+                    for (uint32_t q = 0; q < nb; ++q)
+                        if (status[q] == ST_REP || (winner_key[q] >> 63)) visits_rc += h_rcvis.p[q];
+                // new representatives are numbered in sequence order
+                for (uint32_t q = 0; q < nb; ++q)
+                    if (status[q] == ST_REP) {
+                        cluster_of[b0 + q] = (int32_t)rep_seq.size();
+                        rep_seq.push_back(b0 + q);
+                        S.sum_len_reps += h_len[b0 + q];
+                        S.rep_words += h_wcnt[b0 + q];
+                    }
+                for (uint32_t q = 0; q < nb; ++q)
+                    if (status[q] == ST_MEMBER) cluster_of[b0 + q] = cluster_of[(uint32_t)winner_key[q] & 0x7FFFFFFFu];
                 account(pW, nW);
                 bool fits = true;
                 for (uint32_t i = 0; i < nW; ++i) {
@@ -2712,8 +2717,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 return PGX_OK;
             };
         }
+        const bool trace2 = trace && std::getenv("PGX_TRACE")[0] == '2';
+        if (nt || trace2) {   // (nucleotide windows size their pair buffer from the number of representatives)
+            int rc = deferred(); deferred = nullptr; if (rc) return rc;
+        }
         t_close += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
-        if (trace && std::getenv("PGX_TRACE")[0] == '2')
+        if (trace2)
             fprintf(stderr, "[pgx] window %4llu b0 %8u len %5u..%5u blocks %2llu reps +%5zu (total %7zu) pairs %7u  %.2f ms\n",
                     (unsigned long long)S.sweeps, b0, h_len[b0], h_len[b0 + nb - 1],
                     (unsigned long long)(n_blocks - blocks_before), rep_seq.size() - n_reps, rep_seq.size(), nW,
