@@ -946,14 +946,17 @@ __global__ __launch_bounds__(256) void list_open_kernel(const unsigned long long
 // r; the words it shares with r are among its words that ANY open member of r's part of the window
 // has. The window is cut into <= 32 consecutive CHUNKS of bounded word volume (so that the words of
 // one chunk cover only a fraction of the code space well below the threshold fraction: what unrelated
-// members contribute by chance stays below any threshold, however large the window is), and two
-// tables are filled from the open members' word lists:
-//   chunk_bits[code]      bit t set: some open member of chunk t has the word
-//   first[c][code]        per chunk c: the earliest open member of the chunk that has the word, tagged
+// members contribute by chance stays below any threshold, however large the window is), and one table
+// is filled from the open members' word lists:
+//   first[code][c]        per chunk c: the earliest open member of the chunk that has the word, tagged
 //                         with the round's epoch (epoch << 16 | 65535 - member: a plain atomicMax keeps the
-//                         earliest member of the newest epoch; no per-round reset)
-// For member u of chunk c: the multiplicities of its words whose first[c] tag is earlier than u, and,
-// per earlier chunk t, those of its words with bit t set. When every one of these sums stays below u's
+//                         earliest member of the newest epoch; no per-round reset). The tags of one code
+//                         are adjacent (one record of `stride` words, a 128-byte line for 32 chunks), so the
+//                         test reads, with one access per word, its own chunk's tag and which earlier chunks
+//                         have the word at all (a tag of this epoch). [A separate bit map of chunks per code
+//                         cost a second random access per word in both kernels.]
+// For member u of chunk c: the multiplicities of its words whose first[.][c] tag is earlier than u, and,
+// per earlier chunk t, those of its words that chunk t has. When every one of these sums stays below u's
 // threshold (on both strands), no earlier open member can be its candidate: u is a new
 // representative for certain -- appended to the window's list of new representatives and made final.
 // Typically that is the first member of every family that appears in the window.
@@ -966,18 +969,16 @@ __device__ __forceinline__ uint32_t chunk_of(const Chunks &C, uint32_t ql) {
 }
 __global__ __launch_bounds__(256) void first_open_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
                                                         const uint32_t *__restrict__ n_open, uint32_t b0,
-                                                        uint32_t epoch, uint32_t *__restrict__ first, uint32_t n_codes,
-                                                        uint32_t *__restrict__ chunk_bits, Chunks C) {
+                                                        uint32_t epoch, uint32_t *__restrict__ first, uint32_t stride,
+                                                        Chunks C) {
     const uint32_t lane = threadIdx.x & 63u, n = *n_open;
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
         const uint32_t k = ulist[w], ql = k - b0, c = chunk_of(C, ql);
         const uint64_t o = S.off[k];
-        const uint32_t nw = S.wcnt[k], tag = (epoch << 16) | (65535u - ql), bit = 1u << c;
-        uint32_t *tab = first + (size_t)c * n_codes;
+        const uint32_t nw = S.wcnt[k], tag = (epoch << 16) | (65535u - ql);
         for (uint32_t i = lane; i < nw; i += 64) {   // (members of one family share most words: mostly the reads)
-            const uint32_t code = S.wcode[o + i];
-            if (tab[code] < tag) atomicMax(&tab[code], tag);
-            if (!(chunk_bits[code] & bit)) atomicOr(&chunk_bits[code], bit);
+            uint32_t *slot = first + (size_t)S.wcode[o + i] * stride + c;
+            if (*slot < tag) atomicMax(slot, tag);
         }
     }
 }
@@ -985,8 +986,7 @@ __global__ __launch_bounds__(256) void first_open_kernel(DevSeqs S, const uint32
 __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
                                                      const uint32_t *__restrict__ n_open, uint32_t b0,
                                                      uint32_t both, uint32_t epoch,
-                                                     const uint32_t *__restrict__ first, uint32_t n_codes,
-                                                     const uint32_t *__restrict__ chunk_bits, Chunks C,
+                                                     const uint32_t *__restrict__ first, uint32_t stride, Chunks C,
                                                      const int32_t *__restrict__ req_aan,
                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ list,
                                                      uint32_t *__restrict__ n_list) {
@@ -995,8 +995,6 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
     uint32_t *cnt = s_cnt[threadIdx.x >> 6];
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
         const uint32_t k = ulist[w], ql = k - b0, c = chunk_of(C, ql);
-        const uint32_t *tab = first + (size_t)c * n_codes;
-        const uint32_t earlier = (1u << c) - 1u;
         const int32_t t0 = req_aan[k];
         bool cand = false;
         for (uint32_t strand = 0; strand < (both ? 2u : 1u) && !cand; ++strand) {
@@ -1008,14 +1006,19 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
             __builtin_amdgcn_wave_barrier();
             uint32_t sum = 0;
             for (uint32_t i = lane; i < nw; i += 64) {
-                const uint32_t code = S.wcode[o + i], m = S.wmult[o + i];
-                const uint32_t f = tab[code];
-                if ((f >> 16) == epoch && 65535u - (f & 65535u) < ql) sum += m;
-                uint32_t bits = chunk_bits[code] & earlier;
-                while (bits) {
-                    const uint32_t t = (uint32_t)__builtin_ctz(bits);
-                    bits &= bits - 1u;
-                    atomicAdd(&cnt[t], m);
+                const uint32_t m = S.wmult[o + i];
+                const uint32_t *rec = first + (size_t)S.wcode[o + i] * stride;
+                for (uint32_t t4 = 0; t4 <= c; t4 += 4) {          // (c is the same for the whole wave)
+                    uint32_t v[4];
+                    if (stride >= 4) { const uint4 x = *reinterpret_cast<const uint4 *>(rec + t4); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+                    else { v[0] = rec[0]; v[1] = stride > 1 ? rec[1] : 0u; v[2] = 0u; v[3] = 0u; }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t t = t4 + j;
+                        if (t > c || (v[j] >> 16) != epoch) continue;
+                        if (t < c) atomicAdd(&cnt[t], m);                     // an earlier chunk has the word
+                        else if (65535u - (v[j] & 65535u) < ql) sum += m;    // an earlier member of the own chunk
+                    }
                 }
             }
             for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
@@ -2084,7 +2087,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         return q;
     };
     uint64_t max_window_words = 0;
-    uint32_t max_chunks = 1;   // per-chunk tag tables are only kept for as many chunks as some window has
+    uint32_t max_chunks = 1;   // the tag records are only as long as some window has chunks
     {
         Chunks C;
         for (uint32_t b0 = 0, nbw; b0 < n; b0 += nbw) {
@@ -2099,11 +2102,11 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     const uint32_t gs_stride = 3u * ((max_len + 64u) & ~63u);  // per workgroup: 2 L diagonals + L query positions
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_lines, d_pool[2], d_idx,
-        d_newbits, d_touched, d_first, d_chunkbits, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
+        d_newbits, d_touched, d_first, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
         d_ulist, d_new_list, d_flags, d_gscratch, d_order, d_list, d_gather, d_pk, d_pkoff;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_lines,
-                         &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_chunkbits, &d_best_own, &d_rcvis,
+                         &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_best_own, &d_rcvis,
                          &d_counters, &d_visits, &d_pairsW, &d_pairsK, &d_blk_list, &d_ulist, &d_new_list, &d_flags,
                          &d_gscratch, &d_order, &d_list, &d_gather, &d_pk, &d_pkoff};
         int sl = 1;
@@ -2128,8 +2131,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_idx.alloc(16));
     PGX_HIP(d_newbits.alloc(((size_t)n_codes / 32 + 2) * 4 + 16));
     PGX_HIP(d_touched.alloc((max_window_words + 16) * 4));
-    PGX_HIP(d_first.alloc((size_t)max_chunks * n_codes * 4));   // per-chunk first-open tags
-    PGX_HIP(d_chunkbits.alloc((size_t)n_codes * 4 + 16));
+    uint32_t tag_stride = 1;   // first-open tags: one record of tag_stride >= max_chunks words per code
+    while (tag_stride < max_chunks) tag_stride *= 2;
+    PGX_HIP(d_first.alloc((size_t)tag_stride * n_codes * 4 + 16));
     PGX_HIP(d_best_own.alloc((size_t)window_cap * 8));
     PGX_HIP(d_rcvis.alloc((size_t)window_cap * 8));
     PGX_HIP(d_blk_list.alloc((size_t)kBlockCap * 4));
@@ -2269,7 +2273,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     const uint32_t filter_grid = 4096u;
     uint32_t epoch_idx = 0;      // append rounds of the index (line.epoch); 0 = never
     uint32_t epoch_tag = 0;      // discovery rounds (first-open tags, 16 bits)
-    PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)max_chunks * n_codes * 4, st));
+    PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)tag_stride * n_codes * 4, st));
     phase("window set-up");
     const auto t_loop0 = std::chrono::steady_clock::now();
     double t_resolve = 0.0, t_close = 0.0;
@@ -2406,19 +2410,18 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // the device: the host learns the outcome with the first block's results.
         static const int n_disc = std::getenv("PGX_ROUNDS") ? std::atoi(std::getenv("PGX_ROUNDS")) : kDiscoveryRounds;
         for (int round = 0; round < n_disc; ++round) {
-            if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)max_chunks * n_codes * 4, st)); epoch_tag = 1; }
-            zero_kernel<<<1024, 256, 0, st>>>(d_chunkbits.as<uint4>(), ((size_t)n_codes + 3) / 4);
+            if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)tag_stride * n_codes * 4, st)); epoch_tag = 1; }
             round_begin_kernel<<<1, 1, 0, st>>>(dc);
             list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN);
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "discover_kernels", st);
                 first_open_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
-                                                                                 epoch_tag, d_first.as<uint32_t>(), n_codes,
-                                                                                 d_chunkbits.as<uint32_t>(), chunks);
+                                                                                 epoch_tag, d_first.as<uint32_t>(), tag_stride,
+                                                                                 chunks);
                 certain_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
-                                                                              both ? 1u : 0u, epoch_tag, d_first.as<uint32_t>(), n_codes,
-                                                                              d_chunkbits.as<uint32_t>(), chunks,
+                                                                              both ? 1u : 0u, epoch_tag, d_first.as<uint32_t>(), tag_stride,
+                                                                              chunks,
                                                                               d_aan.as<int32_t>(), d_done, d_new_list.as<uint32_t>(),
                                                                               dc + C_NEW);
             }
