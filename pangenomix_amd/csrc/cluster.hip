@@ -892,8 +892,10 @@ __global__ __launch_bounds__(256) void index_strike_kernel(DevSeqs S, const uint
 // ----------------------------------------------------------------------------------------
 constexpr int kSelThreads = 1024;
 // Pick the next block: the first `block_cap` window members, in order, that are not final (`done`)
-// and have no accepted representative yet. One workgroup, consecutive members per thread, ordered
-// by an exclusive scan. counters[0] = block size, counters[1] = number of such members in total.
+// and have no accepted representative yet. One workgroup; thread t looks at members t, t + 1024, ...
+// (tiles of 1024: all of a thread's loads are independent and in flight together -- consecutive members per
+// thread made this 75 us of dependent loads), ranks come from per-tile, per-wave counts.
+// counters[0] = block size, counters[1] = number of such members in total.
 __global__ __launch_bounds__(kSelThreads) void select_block_kernel(const unsigned long long *__restrict__ best,
                                                                   uint8_t *__restrict__ done,
                                                                   uint8_t *__restrict__ inblk, uint32_t b0,
@@ -903,32 +905,54 @@ __global__ __launch_bounds__(kSelThreads) void select_block_kernel(const unsigne
                                                                   uint32_t *__restrict__ n_k,
                                                                   uint8_t *__restrict__ hascand_accepted,
                                                                   uint32_t window_cap) {
-    __shared__ uint32_t part[kSelThreads];
-    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kTiles = kWindowMax / kSelThreads;      // 64
+    __shared__ uint32_t s_pre[kTiles][16];                      // open members of tile j in the waves before wave w
+    __shared__ uint32_t s_tile[kTiles + 1];                     // ... in the tiles before tile j
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t i = tid; i < 2 * window_cap / 8; i += kSelThreads) reinterpret_cast<unsigned long long *>(hascand_accepted)[i] = 0ull;
     if (tid == 0) *n_k = 0u;
-    const uint32_t per = (nb + kSelThreads - 1) / kSelThreads;
-    const uint32_t q0 = tid * per, q1 = min(nb, q0 + per);
-    uint32_t c = 0;
-    for (uint32_t q = q0; q < q1; ++q) {
-        if (inblk[q]) { done[q] = 1; inblk[q] = 0; }  // retire the previous block
-        c += !done[q] && best[q] == kNoBest;
+    const uint32_t n_tiles = (nb + kSelThreads - 1) / kSelThreads;
+    unsigned long long open = 0ull;                             // bit j: member j * 1024 + tid is open
+#pragma unroll 8
+    for (uint32_t j = 0; j < n_tiles; ++j) {
+        const uint32_t q = j * kSelThreads + tid;
+        if (q >= nb) continue;
+        const uint8_t ib = inblk[q];
+        uint8_t d = done[q];
+        const unsigned long long b = best[q];
+        if (ib) { done[q] = 1; inblk[q] = 0; d = 1; }           // retire the previous block
+        if (!d && b == kNoBest) open |= 1ull << j;
     }
-    part[tid] = c;
+    for (uint32_t j = 0; j < n_tiles; ++j) {
+        const unsigned long long bal = __ballot((open >> j) & 1ull);
+        if (lane == 0) s_pre[j][wave] = (uint32_t)__popcll(bal);
+    }
     __syncthreads();
-    for (uint32_t d = 1; d < kSelThreads; d <<= 1) {
-        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+    {   // thread (j, w): exclusive prefix over the 16 waves of tile j; the tile's total to s_tile
+        const uint32_t j = tid >> 4, w = tid & 15u;
+        const uint32_t c = j < n_tiles ? s_pre[j][w] : 0u;
+        uint32_t incl = c;
+        for (int dd = 1; dd < 16; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd, 16); if ((int)w >= dd) incl += y; }
         __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+        if (j < n_tiles) s_pre[j][w] = incl - c;
+        if (w == 15u) s_tile[j] = incl;
     }
-    uint32_t rank = part[tid] - c;
-    for (uint32_t q = q0; q < q1; ++q) {
-        if (done[q] || best[q] != kNoBest) continue;
-        if (rank < block_cap) { blk_list[rank] = b0 + q; inblk[q] = 1; }
-        ++rank;
+    __syncthreads();
+    if (wave == 0) {   // exclusive prefix over the tiles
+        const uint32_t c = lane < n_tiles ? s_tile[lane] : 0u;
+        uint32_t incl = c;
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if ((int)lane >= dd) incl += y; }
+        s_tile[lane] = incl - c;
+        if (lane == 63u) { s_tile[kTiles] = incl; counters[0] = incl < block_cap ? incl : block_cap; counters[1] = incl; }
     }
-    if (tid == kSelThreads - 1) { counters[0] = part[tid] < block_cap ? part[tid] : block_cap; counters[1] = part[tid]; }
+    __syncthreads();
+    for (uint32_t j = 0; j < n_tiles; ++j) {
+        const bool is_open = (open >> j) & 1ull;
+        const unsigned long long bal = __ballot(is_open);
+        if (!is_open) continue;
+        const uint32_t rank = s_tile[j] + s_pre[j][wave] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (rank < block_cap) { const uint32_t q = j * kSelThreads + tid; blk_list[rank] = b0 + q; inblk[q] = 1; }
+    }
 }
 
 // Start of a discovery round: the window's still-open members (not final, no accepted
