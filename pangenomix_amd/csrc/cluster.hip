@@ -711,6 +711,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     __shared__ unsigned long long s_visits;
     __shared__ uint4 s_stage[4][64];
     if (NEWONLY && *A.d_round_lo >= *A.d_round_hi) return;
+    if (A.qlist && blockIdx.x * 4u >= (A.ns > A.nbq ? 2u : 1u) * *A.d_nq) return;   // (block mode: few members)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     if (threadIdx.x == 0) s_visits = 0ull;
     __syncthreads();
@@ -1474,6 +1475,8 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
     __shared__ uint32_t seqbuf[16 * (kA16Slot / 4) + 32];  // + padding: lanes outside a band may read a few bytes past the last slot
     // one wave per SIMD, bound by its own dependent chain: issue ahead of the side stream's table pass
     __builtin_amdgcn_s_setprio(3);
+    const uint32_t n = sel_count(sel);
+    if (blockIdx.x * 16u >= n) return;   // (a round with few pairs: most workgroups have none; 50 us of table set-up otherwise)
     for (int c = threadIdx.x; c < 4 * kNAA1 * kNAA1; c += 256) {
         const int cc = c % (kNAA1 * kNAA1);
         const int s = S.nt ? (cc / kNAA1 == cc % kNAA1 ? 2 : -2) : (int)kBlosum62_dev[cc];
@@ -1481,7 +1484,6 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
         tab[c / (kNAA1 * kNAA1)][cc] = make_int2(v * 4 + 2, cc / kNAA1 == cc % kNAA1);
     }
     __syncthreads();
-    const uint32_t n = sel_count(sel);
     const int lane = threadIdx.x & 63, gl = lane & 15;
     const int slot = (threadIdx.x >> 6) * 4 + (lane >> 4);
     const uint8_t *sb = reinterpret_cast<const uint8_t *>(seqbuf + slot * (kA16Slot / 4));
