@@ -319,7 +319,7 @@ def main():
         extra.update(kern=kern, terms=terms, cl_bytes=cl_bytes, cl_gbs=cl_gbs, roofline=roofline, roofline_pc=roofline_pc)
 
         cpu = None
-        if not args.skip_cpu:
+        if not args.skip_cpu and world == 1:   # (the CPU baseline is taken at N = 1 only)
             k_g = min(args.cpu_sample_genomes, pset.n_genomes)
             sub = synth.ProteinSet(k_g, pset.cds, pset.F, pset.C, pset.seed)
             sres, soff, _ = sub.nr_arrays()
