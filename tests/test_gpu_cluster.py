@@ -109,6 +109,30 @@ def test_long_posting_lists_and_repeated_words(gpu_ctx):
         assert_same(gpu_ctx.cluster_greedy(res, off, p), oracle.cluster_greedy(res, off, p))
 
 
+def test_short_members_meeting_hundreds_of_new_representatives(gpu_ctx):
+    """A member whose marked words fit one 64-word slab accumulates the representatives it meets straight
+    into the 256-slot exact table (no bucket pass); with several hundred mutually unrelated sequences
+    that share one 22-residue motif -- every one a candidate of every other by word count, none by
+    identity -- that table overflows and the walk falls back to the bounded two-pass scheme with residue
+    classes. Sequences of 58..64 residues: at most 60 words each."""
+    rng = np.random.default_rng(23)
+    motif = rand_seq(rng, 22)
+    seqs = []
+    for _ in range(900):
+        n = int(rng.integers(58, 65))
+        a = int(rng.integers(0, n - 22 + 1))
+        seqs.append(rand_seq(rng, a) + motif + rand_seq(rng, n - 22 - a))
+    seqs += [mutate(rng, seqs[int(i)], int(rng.integers(1, 8))) for i in rng.integers(0, 900, 300)]   # some do join
+    order = rng.permutation(len(seqs))
+    res, off = pack([seqs[i] for i in order])
+    for window in (0, 512):
+        p = params()
+        p.batch_size = window
+        got = gpu_ctx.cluster_greedy(res, off, p)
+        assert_same(got, oracle.cluster_greedy(res, off, p))
+    assert got[4] > 600                                          # (the motif carriers stay apart)
+
+
 def test_dependency_chains_inside_one_window(gpu_ctx):
     """Members that are each other's candidates by word count but not by identity (a chain of ~77 %
     identical variants): none of them is 'certain' before its predecessors are decided, so the
