@@ -993,16 +993,26 @@ __device__ __forceinline__ uint32_t chunk_of(const Chunks &C, uint32_t ql) {
 __global__ __launch_bounds__(256) void first_open_kernel(DevSeqs S, const uint32_t *__restrict__ ulist,
                                                         const uint32_t *__restrict__ n_open, uint32_t b0,
                                                         uint32_t epoch, uint32_t *__restrict__ first, uint32_t stride,
-                                                        Chunks C) {
+                                                        Chunks C, const int32_t *__restrict__ req_aan,
+                                                        uint8_t *__restrict__ decided) {
     const uint32_t lane = threadIdx.x & 63u, n = *n_open;
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
         const uint32_t k = ulist[w], ql = k - b0, c = chunk_of(C, ql);
         const uint64_t o = S.off[k];
         const uint32_t nw = S.wcnt[k], tag = (epoch << 16) | (65535u - ql);
+        // Tags only ever move to earlier members, so the words that carry an earlier member's tag NOW are a
+        // lower bound of what certain_kernel will count for this member's own chunk: at the threshold already,
+        // the member has an earlier open candidate for sure and that kernel need not look at it (members come
+        // roughly in order, so this settles most members of a family but its first)
+        uint32_t sum = 0;
         for (uint32_t i = lane; i < nw; i += 64) {   // (members of one family share most words: mostly the reads)
             uint32_t *slot = first + (size_t)S.wcode[o + i] * stride + c;
-            if (*slot < tag) atomicMax(slot, tag);
+            const uint32_t v = *slot;
+            if (v < tag) atomicMax(slot, tag);
+            else if (v > tag && (v >> 16) == epoch) sum += S.wmult[o + i];
         }
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) decided[ql] = sum != 0u && (int32_t)sum >= req_aan[k];
     }
 }
 // One wave per open member.
@@ -1011,13 +1021,16 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
                                                      uint32_t both, uint32_t epoch,
                                                      const uint32_t *__restrict__ first, uint32_t stride, Chunks C,
                                                      const int32_t *__restrict__ req_aan,
+                                                     const uint8_t *__restrict__ decided,
                                                      uint8_t *__restrict__ done, uint32_t *__restrict__ list,
                                                      uint32_t *__restrict__ n_list) {
     __shared__ uint32_t s_cnt[4][kMaxChunks];
     const uint32_t lane = threadIdx.x & 63u, n = *n_open;
     uint32_t *cnt = s_cnt[threadIdx.x >> 6];
     for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < n; w += gridDim.x * 4) {
-        const uint32_t k = ulist[w], ql = k - b0, c = chunk_of(C, ql);
+        const uint32_t k = ulist[w], ql = k - b0;
+        if (decided[ql]) continue;               // (first_open_kernel: an earlier open candidate for sure)
+        const uint32_t c = chunk_of(C, ql);
         const int32_t t0 = req_aan[k];
         bool cand = false;
         for (uint32_t strand = 0; strand < (both ? 2u : 1u) && !cand; ++strand) {
@@ -2443,11 +2456,11 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 ProfScope prof(ctx, "discover_kernels", st);
                 first_open_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
                                                                                  epoch_tag, d_first.as<uint32_t>(), tag_stride,
-                                                                                 chunks);
+                                                                                 chunks, d_aan.as<int32_t>(), d_accepted);
                 certain_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
                                                                               both ? 1u : 0u, epoch_tag, d_first.as<uint32_t>(), tag_stride,
                                                                               chunks,
-                                                                              d_aan.as<int32_t>(), d_done, d_new_list.as<uint32_t>(),
+                                                                              d_aan.as<int32_t>(), d_accepted, d_done, d_new_list.as<uint32_t>(),
                                                                               dc + C_NEW);
             }
             LAUNCH_CHECK();
