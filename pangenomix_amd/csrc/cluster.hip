@@ -64,6 +64,7 @@ constexpr uint32_t kBlockCapMin = 64;  // what a block shrinks to when its candi
 constexpr uint32_t kMaxLen = 32767;    // longest supported sequence
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kDiagLdsCap = 2048;  // diagonals / query 2-mers kept in LDS by the diag kernel
+constexpr uint32_t kDiagLdsSmall = 512; // ... for windows whose queries are that short (most of them)
 constexpr int kMaxBand = 64;
 
 __constant__ int8_t kBlosum62_dev[kNAA1 * kNAA1] = PGXC_BLOSUM62_FLAT;
@@ -1273,16 +1274,19 @@ __device__ __forceinline__ int kd_code(const DevSeqs &S, const uint8_t *__restri
 }
 
 // rep_seq == nullptr: p.r is already a sequence index (phase B)
+// CAP: diagonals / query 2-mers kept in LDS (larger pairs use the global scratch): 512 gives six waves per SIMD
+// where 2048 gives three -- a pair of 340-residue sequences at 0.8 identity needs 140 diagonals and 340 positions
+template <uint32_t CAP>
 __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
                                                  Pair *__restrict__ pairs, PairSel sel,
                                                  const int32_t *__restrict__ req_aa1,
                                                  const int32_t *__restrict__ req_aas, int band_width,
                                                  double cluster_thd, uint32_t *__restrict__ gscratch,
                                                  uint32_t gscratch_stride) {
-    __shared__ uint32_t diag[kDiagLdsCap];
+    __shared__ uint32_t diag[CAP];
     __shared__ uint32_t taap[kNAA1 * kNAA1 + 7];
     __shared__ uint32_t abeg[kNAA1 * kNAA1 + 7];
-    __shared__ uint16_t alist[kDiagLdsCap];
+    __shared__ uint16_t alist[CAP];
     const uint32_t lane = threadIdx.x;
     const uint32_t np = sel_count(sel);
     const int N2 = S.nt ? 256 : kNAA1 * kNAA1;
@@ -1303,7 +1307,7 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
         const int d_lo = req_aa1[k1r] - 1 >= 0 ? req_aa1[k1r] - 1 : 0;
         const int d_hi = nall - d_lo;
         const int n_d = d_hi >= d_lo ? d_hi - d_lo + 1 : 0;
-        const bool big = (uint32_t)n_d > kDiagLdsCap || (uint32_t)len1 > kDiagLdsCap;
+        const bool big = (uint32_t)n_d > CAP || (uint32_t)len1 > CAP;
         uint32_t *dg = big ? gscratch + (size_t)blockIdx.x * gscratch_stride : diag;
         // the query's 2-mer position lists (global scratch tail for oversized queries)
         uint32_t *al_big = big ? dg + 2 * (gscratch_stride / 3) : nullptr;  // stride = 3 x (longest sequence, rounded up)
@@ -2134,7 +2138,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         }
     }
     PGX_REQUIRE(max_window_words < 0xFFFFFFF0ull, "window too large");
-    const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsCap;
+    const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsSmall;
     const uint32_t diag_grid = 8192, align_grid = 1024;  // diag: one wave per pair, ~11 workgroups fit a CU
     const uint32_t gs_stride = 3u * ((max_len + 64u) & ~63u);  // per workgroup: 2 L diagonals + L query positions
 
@@ -2365,8 +2369,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             const uint32_t ag = grid_hint ? std::min(align_grid, (grid_hint + 15) / 16) : align_grid;
             {
                 ProfScope prof(ctx, "diag_kernel", st);
-                diag_kernel<<<dg, 64, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
-                                               P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+                auto kern = h_len[b0] <= kDiagLdsSmall ? diag_kernel<kDiagLdsSmall> : diag_kernel<kDiagLdsCap>;
+                kern<<<dg, 64, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
+                                        P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride);
             }
             LAUNCH_CHECK();
             {
