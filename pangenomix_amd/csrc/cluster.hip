@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void zero_kernel(uint4 *__restrict__ p, size_t
 // [3] block size, [4] open members, [5] new representatives of the window (list length),
 // [6] begin of the current round's segment of that list, [7] touched codes of the round,
 // [8] error flag, [9] open members of the round
-enum { C_NW = 0, C_NK = 1, C_EVAL0 = 2, C_BLK = 3, C_OPEN = 4, C_NEW = 5, C_SEG0 = 6, C_TOUCH = 7, C_ERR = 8, C_ROUND_OPEN = 9, C_ZERO = 10, C_COUNT = 16 };
+enum { C_NW = 0, C_NK = 1, C_EVAL0 = 2, C_BLK = 3, C_OPEN = 4, C_NEW = 5, C_SEG0 = 6, C_TOUCH = 7, C_ERR = 8, C_ROUND_OPEN = 9, C_ZERO = 10, C_WIDE = 11, C_COUNT = 16 };
 
 // block members are final once the host has walked the block (final = 0: the block is given up, see the host)
 __global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb, uint32_t final_) {
@@ -1282,7 +1282,8 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
                                                  const int32_t *__restrict__ req_aa1,
                                                  const int32_t *__restrict__ req_aas, int band_width,
                                                  double cluster_thd, uint32_t *__restrict__ gscratch,
-                                                 uint32_t gscratch_stride) {
+                                                 uint32_t gscratch_stride, uint32_t *__restrict__ n_wide) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_wide = 0u;   // (pairs that the 16-lane aligner, which runs next, leaves to align_kernel)
     __shared__ uint32_t diag[CAP];
     __shared__ uint32_t taap[kNAA1 * kNAA1 + 7];
     __shared__ uint32_t abeg[kNAA1 * kNAA1 + 7];
@@ -1444,7 +1445,7 @@ __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__
 
 // ----------------------------------------------------------------------------------------
 // align16: the same recurrence for the common case (band <= 32 diagonals, len1 + len2 <=
-// kA16MaxSum), four pairs per wave.
+// slot - 96), four pairs per wave.
 //
 //   * one pair per DPP row of 16 lanes; lane g owns band columns 2g and 2g+1, so every lane
 //     computes one cell on every step of the anti-diagonal wavefront (no idle parity) and
@@ -1459,8 +1460,12 @@ __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__
 //   * border cells (row 0 / column 0 of the DP matrix) are produced by the same lanes as
 //     forced values, so interior cells never special-case their neighbours.
 // ----------------------------------------------------------------------------------------
-constexpr int kA16Slot = 4096;     // LDS bytes per pair
-constexpr int kA16MaxSum = 4000;   // len1 + len2 handled by the fast path (both, 6-padded, fit the slot)
+// LDS bytes per pair: a template parameter (1024 / 2048 / 4096), chosen per window from its longest query. The
+// kernel is bound by each pair's dependent chain, so what counts is waves per SIMD: 30 KB of LDS per workgroup
+// with 1 KB slots = five, 78 KB with 4 KB slots = two (17.8 -> 8.8 ms per step for the windows of cfg-3s that fit).
+// len1 + len2 <= slot - 96 is handled here (both sequences, 6-padded, fit the slot); the rest, and bands over 32
+// diagonals, are counted in *n_wide and left to align_kernel.
+constexpr int kA16MaxSlot = 4096;
 constexpr int kScaleShift = 14;
 
 __device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
@@ -1475,15 +1480,16 @@ __device__ __forceinline__ uint32_t lane_select(uint64_t mask, uint32_t if_set, 
 }
 __device__ __forceinline__ uint64_t lanes_equal(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32 /* ICMP_EQ */); }
 
-__device__ __forceinline__ bool pair_is_wide(int len1, int len2, int bl, int br) {
-    return len1 + len2 > kA16MaxSum || br - bl + 1 > 32;
+__device__ __forceinline__ bool pair_is_wide(int len1, int len2, int bl, int br, int max_sum) {
+    return len1 + len2 > max_sum || br - bl + 1 > 32;
 }
 
+template <int kA16Slot>
 __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
                                                      Pair *__restrict__ pairs, PairSel sel,
                                                      const int32_t *__restrict__ req_aa1, double cluster_thd,
                                                      uint32_t b0, unsigned long long *__restrict__ best,
-                                                     uint32_t key_flag) {
+                                                     uint32_t key_flag, uint32_t *__restrict__ n_wide) {
     // substitution score + centre bonus in key form (value * 4 + 2, see the interior rows) and the
     // identity bit, one 8-byte entry per residue pair and bonus class
     __shared__ int2 tab[4][kNAA1 * kNAA1];
@@ -1517,8 +1523,11 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
             pr = pairs[p];
             k1 = pr.q; k2 = rep_seq ? rep_seq[pr.r] : pr.r;
             len1 = (int)S.len[k1]; len2 = (int)S.len[k2];
-            fast = (pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG | F_ALIGNED)) == (F_DIAG_PASS | F_BAND_OK) &&
-                   !pair_is_wide(len1, len2, pr.band_left, pr.band_right);
+            fast = (pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG | F_ALIGNED)) == (F_DIAG_PASS | F_BAND_OK);
+            if (fast && pair_is_wide(len1, len2, pr.band_left, pr.band_right, kA16Slot - 96)) {
+                fast = false;
+                if (gl == 0) atomicAdd(n_wide, 1u);      // left to align_kernel
+            }
         }
         const int bl = pr.band_left, bw = fast ? pr.band_right - pr.band_left + 1 : 0;
         // ---- stage both sequences: coalesced loads of the 5-bit packed words, unpacked into LDS bytes ----
@@ -1715,8 +1724,10 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
                                                    Pair *__restrict__ pairs, PairSel sel,
                                                    const int32_t *__restrict__ req_aa1, double cluster_thd,
                                                    uint32_t b0, unsigned long long *__restrict__ best,
-                                                   uint32_t key_flag, int wide_only) {
+                                                   uint32_t key_flag, int wide_only, int max_sum,
+                                                   const uint32_t *__restrict__ n_wide) {
     __shared__ int8_t sub[kNAA1 * kNAA1];
+    if (wide_only && *n_wide == 0u) return;      // (nearly always: align16_kernel has met no pair it cannot take)
     for (int c = threadIdx.x; c < kNAA1 * kNAA1; c += 256)
         sub[c] = S.nt ? (int8_t)(c / kNAA1 == c % kNAA1 ? 2 : -2) : kBlosum62_dev[c];
     __syncthreads();
@@ -1729,7 +1740,7 @@ __global__ __launch_bounds__(256) void align_kernel(DevSeqs S, const uint32_t *_
         if ((pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG | F_ALIGNED)) != (F_DIAG_PASS | F_BAND_OK)) continue;
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
         const int len1 = (int)S.len[k1], len2 = (int)S.len[k2];
-        if (wide_only && !pair_is_wide(len1, len2, pr.band_left, pr.band_right)) continue;
+        if (wide_only && !pair_is_wide(len1, len2, pr.band_left, pr.band_right, max_sum)) continue;
         const int iden = band_align_wave(S.res + S.off[k1], S.res + S.off[k2], len1, len2, pr.band_left,
                                          pr.band_center, pr.band_right, sub, gap_open, gap_ext);
         const uint32_t k1r = real_of(S, k1);
@@ -2350,7 +2361,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         const uint64_t blocks_before = n_blocks;
         // the general (int64, one pair per wave) aligner is only needed when some pair of this
         // window cannot use the 16-lane fast path: query length + longest sequence, or the band
-        const bool any_wide = P->band_width > 32 || (int)(h_len[b0] + max_len) > kA16MaxSum;
+        // LDS slot per pair of the 16-lane aligner: sized for two sequences as long as the window's longest query
+        const int a16_slot = 2 * (int)h_len[b0] <= 1024 - 96 ? 1024 : (2 * (int)h_len[b0] <= 2048 - 96 ? 2048 : kA16MaxSlot);
         Pair *pairsW = d_pairsW.as<Pair>();
         FilterArgs FA{};
         FA.lines = d_lines.as<IndexLine>(); FA.pool = d_poolp; FA.newbits = d_newbits.as<uint32_t>();
@@ -2371,16 +2383,15 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 ProfScope prof(ctx, "diag_kernel", st);
                 auto kern = h_len[b0] <= kDiagLdsSmall ? diag_kernel<kDiagLdsSmall> : diag_kernel<kDiagLdsCap>;
                 kern<<<dg, 64, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
-                                        P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride);
+                                        P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride, dc + C_WIDE);
             }
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "align_kernel", st);
-                align16_kernel<<<ag, 256, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0,
-                                                   best_arr, 0u);
-                if (any_wide)
-                    align_kernel<<<grid_hint ? std::min(align_grid, (grid_hint + 3) / 4) : align_grid, 256, 0, st>>>(
-                        DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, 1);
+                auto kern = a16_slot == 1024 ? align16_kernel<1024> : (a16_slot == 2048 ? align16_kernel<2048> : align16_kernel<kA16MaxSlot>);
+                kern<<<ag, 256, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, dc + C_WIDE);
+                align_kernel<<<grid_hint ? std::min(align_grid, (grid_hint + 3) / 4) : align_grid, 256, 0, st>>>(
+                    DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, 1, a16_slot - 96, dc + C_WIDE);
             }
             LAUNCH_CHECK();
             return PGX_OK;
