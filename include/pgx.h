@@ -287,6 +287,10 @@ int pgx_legacy_shuffles(uint32_t *key, int32_t *pos, uint32_t n, uint32_t n_iter
  * <prefix><cluster>[<variant><member>]; variant NULL = gene names */
 int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
                       uint64_t n, uint32_t width, char *out);
+/* the same names as numpy 'U<width>' records (UCS-4 code points, zero padded; prefix and variant ASCII, numbers >= 0,
+ * width <= 64), written by several threads */
+int pgx_format_labels_ucs4(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
+                           uint64_t n, uint32_t width, uint32_t *out);
 
 #ifdef __cplusplus
 }

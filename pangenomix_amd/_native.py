@@ -77,6 +77,7 @@ SIGNATURES = {
     'pgx_fasta_write_consolidated': (C.c_int, [_P, _S, _S, _S]),
     'pgx_legacy_shuffles': (C.c_int, [_P, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, _P]),
     'pgx_format_labels': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
+    'pgx_format_labels_ucs4': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_fasta_write_clustered': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _S, _S, _S, _S, _S]),
     'pgx_version': (C.c_int, []),
     'pgx_last_error': (C.c_char_p, []),
@@ -399,11 +400,22 @@ def format_labels(prefix, cluster, member=None, variant=None):
     cluster = np.ascontiguousarray(cluster, dtype=np.int32)
     if variant is not None:
         member = np.ascontiguousarray(member, dtype=np.int32)
+    digits = lambda a: len(str(int(a.max()))) if a.size else 1   # noqa: E731
+    if prefix.isascii() and (variant is None or variant.isascii()) and (cluster.size == 0 or int(cluster.min()) >= 0) \
+            and (variant is None or member.size == 0 or int(member.min()) >= 0):
+        # straight into numpy's own 'U' layout (UCS-4), exact width, several threads
+        width = len(prefix) + digits(cluster) + (len(variant) + digits(member) if variant is not None else 0)
+        if width <= 64:
+            out = np.zeros(cluster.size, dtype='U%d' % width)
+            check(lib().pgx_format_labels_ucs4(prefix.encode(), variant.encode() if variant is not None else None,
+                                               _ptr(cluster), _ptr(member) if variant is not None else None,
+                                               cluster.size, width, _ptr(out)))
+            return out
     width = len(prefix.encode()) + 11 + (len(variant) + 11 if variant is not None else 0)
     out = np.zeros(cluster.size, dtype='S%d' % width)
     check(lib().pgx_format_labels(prefix.encode(), variant.encode() if variant is not None else None, _ptr(cluster),
                                   _ptr(member) if variant is not None else None, cluster.size, width, _ptr(out)))
-    return out.astype('U')
+    return np.char.decode(out, 'utf-8')
 
 
 _default_ctx = None

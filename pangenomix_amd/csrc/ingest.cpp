@@ -353,32 +353,64 @@ int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pg
     lap("headers");
     // first-seen exact de-duplication, in the order given (files, then records): open addressing on the
     // digest's first 8 bytes, full 32-byte compare
-    size_t cap = 16;
-    while (cap < 2 * (size_t)R + 16) cap <<= 1;
-    std::vector<int64_t> table(cap, -1);   // -> group
+    // Partitioned by digest: thread p owns the records whose digest falls into its share of the hash space and
+    // finds, for each of them in record order, the first record with the same digest (its own table: no
+    // sharing); the groups are then numbered in one sequential pass over the records, which needs no hashing.
+    const unsigned n_part = (unsigned)std::max(1, std::min(n_threads, 16));
+    auto digest_of = [&](uint64_t g) -> const uint8_t * {
+        const Rec &rc = S->rec(g);
+        return &S->files[rc.file].digest[(g - S->first_rec[rc.file]) * 32];
+    };
+    std::vector<uint64_t> first_same(R);   // record -> first record with the same sequence
+    parallel_for(n_part, (int)n_part, [&](size_t part) {
+        size_t cap = 16;
+        while (cap < 2 * ((size_t)R / n_part + 1) + 16) cap <<= 1;
+        std::vector<int64_t> table(cap, -1);   // -> record
+        for (uint64_t g = 0; g < R; ++g) {
+            const Rec &rc = S->rec(g);
+            if (!rc.hdr_len || !rc.seq_len) continue;
+            const uint8_t *d = digest_of(g);
+            uint64_t h;
+            memcpy(&h, d, 8);
+            h *= 0x9E3779B97F4A7C15ull;
+            if ((unsigned)((h >> 40) % n_part) != part) continue;
+            size_t slot = (size_t)h & (cap - 1);
+            for (size_t probes = 0;; ++probes) {
+                const int64_t t = table[slot];
+                if (t < 0) { table[slot] = (int64_t)g; first_same[g] = g; break; }
+                if (memcmp(digest_of((uint64_t)t), d, 32) == 0) { first_same[g] = (uint64_t)t; break; }
+                slot = (slot + 1) & (cap - 1);
+                if (probes > cap / 2) {   // (a skewed partition: grow and re-insert)
+                    std::vector<int64_t> bigger(cap * 2, -1);
+                    for (int64_t e : table) if (e >= 0) {
+                        uint64_t hh; memcpy(&hh, digest_of((uint64_t)e), 8); hh *= 0x9E3779B97F4A7C15ull;
+                        size_t sl = (size_t)hh & (cap * 2 - 1);
+                        while (bigger[sl] >= 0) sl = (sl + 1) & (cap * 2 - 1);
+                        bigger[sl] = e;
+                    }
+                    table.swap(bigger); cap *= 2; slot = (size_t)h & (cap - 1); probes = 0;
+                }
+            }
+        }
+    });
     for (uint64_t g = 0; g < R; ++g) {
         const Rec &rc = S->rec(g);
         if (!rc.hdr_len) { S->group_of[g] = -2; continue; }      // a sequence without a name
         if (!rc.seq_len) { ++S->n_missing; continue; }
-        const uint8_t *d = &S->files[rc.file].digest[(g - S->first_rec[rc.file]) * 32];
-        uint64_t h;
-        memcpy(&h, d, 8);
-        size_t slot = (size_t)(h * 0x9E3779B97F4A7C15ull) & (cap - 1);
-        for (;;) {
-            const int64_t t = table[slot];
-            if (t < 0) {
-                table[slot] = (int64_t)S->rep_of_group.size();
-                S->group_of[g] = (int32_t)S->rep_of_group.size();
-                S->rep_of_group.push_back(g);
-                S->digests.insert(S->digests.end(), d, d + 32);
-                break;
-            }
-            if (memcmp(&S->digests[(size_t)t * 32], d, 32) == 0) { S->group_of[g] = (int32_t)t; break; }
-            slot = (slot + 1) & (cap - 1);
+        if (first_same[g] == g) {
+            S->group_of[g] = (int32_t)S->rep_of_group.size();
+            S->rep_of_group.push_back(g);
+        } else {
+            S->group_of[g] = S->group_of[first_same[g]];
         }
     }
     S->n_groups = S->rep_of_group.size();
     const uint64_t G = S->n_groups;
+    S->digests.resize(G * 32);
+    parallel_for((size_t)((G + 4095) / 4096), n_threads, [&](size_t c) {
+        for (uint64_t k = c * 4096; k < std::min<uint64_t>(G, (c + 1) * 4096); ++k)
+            memcpy(&S->digests[k * 32], digest_of(S->rep_of_group[k]), 32);
+    });
     lap("de-duplication");
     // the groups' members in encounter order (CSR) and the sequences handed to the clustering call
     S->members_off.assign(G + 1, 0);
@@ -409,26 +441,46 @@ int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pg
     // string (pangenome.py:505-521, :649); a header that names two different sequences is resolved there by
     // insertion order. Such inputs are left to the Python path.
     {
-        size_t hc = 16;
-        while (hc < 2 * (size_t)R + 16) hc <<= 1;
-        std::vector<int64_t> ht(hc, -1);   // -> a record with that header
-        for (uint64_t g = 0; g < R && S->simple; ++g) {
-            if (S->group_of[g] < 0) continue;
-            const char *h = &S->hdr_blob[S->hdr_off[g]];
-            const size_t hl = (size_t)(S->hdr_off[g + 1] - S->hdr_off[g]);
-            uint64_t x = 1469598103934665603ull;
-            for (size_t i = 0; i < hl; ++i) x = (x ^ (unsigned char)h[i]) * 1099511628211ull;
-            size_t slot = (size_t)(x * 0x9E3779B97F4A7C15ull) & (hc - 1);
-            for (;;) {
-                const int64_t t = ht[slot];
-                if (t < 0) { ht[slot] = (int64_t)g; break; }
-                const size_t tl = (size_t)(S->hdr_off[t + 1] - S->hdr_off[t]);
-                if (tl == hl && memcmp(&S->hdr_blob[S->hdr_off[t]], h, hl) == 0) {
-                    if (S->group_of[t] != S->group_of[g]) { S->simple = false; S->why = "header '" + std::string(h, hl) + "' names two different sequences"; }
-                    break;
-                }
-                slot = (slot + 1) & (hc - 1);
+        std::vector<uint64_t> hhash(R);
+        parallel_for((size_t)((R + 65535) / 65536), n_threads, [&](size_t c) {
+            for (uint64_t g = c * 65536; g < std::min<uint64_t>(R, (c + 1) * 65536); ++g) {
+                const char *h = &S->hdr_blob[S->hdr_off[g]];
+                const size_t hl = (size_t)(S->hdr_off[g + 1] - S->hdr_off[g]);
+                uint64_t x = 1469598103934665603ull;
+                for (size_t i = 0; i < hl; ++i) x = (x ^ (unsigned char)h[i]) * 1099511628211ull;
+                hhash[g] = x * 0x9E3779B97F4A7C15ull;
             }
+        });
+        std::vector<int64_t> clash(n_part, -1);   // per partition: the first record whose header names another sequence too
+        parallel_for(n_part, (int)n_part, [&](size_t part) {
+            size_t hc = 16;
+            while (hc < 4 * ((size_t)R / n_part + 1) + 16) hc <<= 1;
+            std::vector<int64_t> ht(hc, -1);   // -> a record with that header
+            for (uint64_t g = 0; g < R; ++g) {
+                if (S->group_of[g] < 0 || (unsigned)((hhash[g] >> 40) % n_part) != part) continue;
+                const char *h = &S->hdr_blob[S->hdr_off[g]];
+                const size_t hl = (size_t)(S->hdr_off[g + 1] - S->hdr_off[g]);
+                size_t slot = (size_t)hhash[g] & (hc - 1);
+                for (size_t probes = 0;; ++probes) {
+                    const int64_t t = ht[slot];
+                    if (t < 0) { ht[slot] = (int64_t)g; break; }
+                    const size_t tl = (size_t)(S->hdr_off[t + 1] - S->hdr_off[t]);
+                    if (tl == hl && memcmp(&S->hdr_blob[S->hdr_off[t]], h, hl) == 0) {
+                        if (S->group_of[t] != S->group_of[g] && clash[part] < 0) clash[part] = (int64_t)g;
+                        break;
+                    }
+                    slot = (slot + 1) & (hc - 1);
+                    if (probes > hc / 2) { clash[part] = (int64_t)g; return; }   // (hopelessly skewed: leave it to the Python path)
+                }
+                if (clash[part] >= 0) return;
+            }
+        });
+        int64_t first_clash = -1;
+        for (int64_t c : clash) if (c >= 0 && (first_clash < 0 || c < first_clash)) first_clash = c;
+        if (first_clash >= 0) {
+            const char *h = &S->hdr_blob[S->hdr_off[first_clash]];
+            S->simple = false;
+            S->why = "header '" + std::string(h, (size_t)(S->hdr_off[first_clash + 1] - S->hdr_off[first_clash])) + "' names two different sequences";
         }
     }
     lap("header check");
@@ -645,6 +697,43 @@ int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cl
         memcpy(o + pl, num, (size_t)k);
         memset(o + pl + k, 0, width - pl - (size_t)k);
     }
+    return PGX_OK;
+}
+
+/* the same names as numpy 'U<width>' records (UCS-4 code points, zero padded), written by several threads;
+ * prefix and variant must be ASCII */
+int pgx_format_labels_ucs4(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
+                           uint64_t n, uint32_t width, uint32_t *out) {
+    if (!prefix || !cluster || (variant && !member) || (n && !out)) { pgx_set_error("pgx_format_labels_ucs4: NULL argument"); return PGX_ERR_INVALID; }
+    const size_t pl = strlen(prefix), vl = variant ? strlen(variant) : 0;
+    for (size_t i = 0; i < pl; ++i) if ((unsigned char)prefix[i] >= 128) { pgx_set_error("pgx_format_labels_ucs4: prefix is not ASCII"); return PGX_ERR_INVALID; }
+    for (size_t i = 0; i < vl; ++i) if ((unsigned char)variant[i] >= 128) { pgx_set_error("pgx_format_labels_ucs4: variant is not ASCII"); return PGX_ERR_INVALID; }
+    std::atomic<int> bad{0};
+    const size_t chunk = 1u << 15;
+    parallel_for((size_t)((n + chunk - 1) / chunk), (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())), [&](size_t c) {
+        auto put_int = [](uint32_t *o, int32_t v) -> size_t {     // decimal digits of v >= 0 (names never hold negatives)
+            char tmp[12];
+            size_t k = 0;
+            uint32_t u = v < 0 ? 0u : (uint32_t)v;
+            do { tmp[k++] = (char)('0' + u % 10u); u /= 10u; } while (u);
+            for (size_t i = 0; i < k; ++i) o[i] = (uint32_t)tmp[k - 1 - i];
+            return k;
+        };
+        for (uint64_t i = c * chunk; i < std::min<uint64_t>(n, (c + 1) * chunk); ++i) {
+            uint32_t *o = out + i * width, rec[64];
+            size_t k = 0;
+            if (pl + vl + 24 > 64 + (size_t)0 || width > 64) { bad = 1; return; }
+            for (size_t t = 0; t < pl; ++t) rec[k++] = (uint32_t)(unsigned char)prefix[t];
+            k += put_int(rec + k, cluster[i]);
+            if (variant) {
+                for (size_t t = 0; t < vl; ++t) rec[k++] = (uint32_t)(unsigned char)variant[t];
+                k += put_int(rec + k, member[i]);
+            }
+            if (k > width) { bad = 2; return; }
+            for (size_t t = 0; t < width; ++t) o[t] = t < k ? rec[t] : 0u;
+        }
+    });
+    if (bad) { pgx_set_error("pgx_format_labels_ucs4: %s", bad == 2 ? "width too small" : "labels longer than 64 characters"); return PGX_ERR_INVALID; }
     return PGX_OK;
 }
 

@@ -39,8 +39,8 @@ class LightSparseDataFrame(object):
         # and leaves .data = nan there; here it is an error (the
         # build raises where the reference prints and continues).
         self.data = data.tocoo()
-        self.index = np.array(index)
-        self.columns = np.array(columns)
+        self.index = np.asarray(index)       # (label arrays of a million names are not copied again)
+        self.columns = np.asarray(columns)
         self.shape = self.data.shape
         self._index_map = self._column_map = None   # label -> position, built on first use (:199-200)
         if len(index) != self.shape[0]:
@@ -70,9 +70,10 @@ class LightSparseDataFrame(object):
         label_path = npz_file + '.labels.txt' if label_file is None else label_file
         with open(label_path, 'w+') as f:
             for labels in (self.index, self.columns):
+                is_str = getattr(getattr(labels, 'dtype', None), 'kind', None) == 'U'
                 labels = labels.tolist() if hasattr(labels, 'tolist') else list(labels)
                 if labels:
-                    f.write('\n'.join(str(x) for x in labels) + '\n')
+                    f.write('\n'.join(labels if is_str else [str(x) for x in labels]) + '\n')
         m = self.data.tocoo()
         members = (('row', m.row), ('col', m.col), ('format', np.array(m.format.encode('ascii'))),
                    ('shape', np.array(m.shape, dtype=np.int64)), ('data', m.data))
