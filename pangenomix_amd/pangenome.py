@@ -401,15 +401,17 @@ def _lex_key(values, shorter_first):
     followed by the variant letter 'A', which sorts after every digit: C100 < C10 < C1, reference
     :615)."""
     v = np.asarray(values, dtype=np.int64)
-    nd = np.ones(v.shape, dtype=np.int64)
-    for p in range(1, 10):
-        nd += v >= 10 ** p
-    key = np.zeros(v.shape, dtype=np.int64)
-    pad = 0 if shorter_first else 11
-    for p in range(10):
-        digit = (v // 10 ** np.maximum(nd - 1 - p, 0)) % 10 + 1
-        key = key * 12 + np.where(p < nd, digit, pad)
-    return key
+    pow10 = 10 ** np.arange(1, 19, dtype=np.int64)
+    nd = np.searchsorted(pow10, v, side='right') + 1             # number of decimal digits
+    width = int(nd.max()) if nd.size else 1
+    # digits left-aligned to the longest number, padded with zeros where the name ends after the number (a shorter
+    # string sorts first: 1 < 10 < 100) and with nines where the letter follows (it sorts after every digit:
+    # 19A < 1A, and among equals the longer first: 100A < 10A < 1A); the digit count breaks the ties that
+    # padding creates (all lengths are at most 18: 5 bits)
+    scale = np.concatenate(([1], pow10))[width - nd]
+    if shorter_first:
+        return v * scale * 32 + nd
+    return ((v + 1) * scale - 1) * 32 + (31 - nd)
 
 
 def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, cluster_type, cdhit_args,
@@ -466,7 +468,11 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         genome_order = sorted(genomes)
         print('Sorting alleles...')
         clustered = np.flatnonzero(cl >= 0)
-        order = np.lexsort((_lex_key(mem[clustered], True), _lex_key(cl[clustered], False)))
+        k_mem, k_cl = _lex_key(mem[clustered], True), _lex_key(cl[clustered], False)
+        if k_mem.size and int(k_mem.max()).bit_length() + int(k_cl.max()).bit_length() <= 62:   # one key, one sort
+            order = np.argsort((k_cl << int(k_mem.max()).bit_length()) | k_mem, kind='stable')
+        else:
+            order = np.lexsort((k_mem, k_cl))
         allele_groups = clustered[order]                       # groups in allele-row order
         row_of_group = np.full(fs.n_groups, -1, dtype=np.int64)
         row_of_group[allele_groups] = np.arange(allele_groups.size)
@@ -485,7 +491,11 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         path_rank[np.argsort(np.array(genome_paths, dtype=object), kind='stable')] = np.arange(len(genome_paths))
         genome_of_file = np.array([genome_order.index(g) for g in genomes], dtype=np.int64)
         file_of = fs.file_of_record.astype(np.int64)
-        recs = np.argsort(path_rank[file_of], kind='stable')
+        # (records are stored file after file: the stable sort by file rank is a concatenation of whole ranges)
+        starts = np.searchsorted(file_of, np.arange(len(genome_paths) + 1))
+        by_rank = np.argsort(path_rank, kind='stable')
+        recs = np.concatenate([np.arange(starts[f], starts[f + 1], dtype=np.int64) for f in by_rank]) \
+            if file_of.size else np.zeros(0, dtype=np.int64)
         grp = fs.group_of_record[recs]
         seen = grp != -1                                       # (-2: a sequence without a name, 'MISSING: ' below)
         recs, grp = recs[seen], grp[seen]
