@@ -2012,6 +2012,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_REQUIRE(in_len.ok(), "out of host memory");
     PGX_HIP(hipMemcpyAsync(in_len.data(), d_in_len.p, (size_t)n_in * 4, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));
+    phase("  seq_len kernel + copy");
     uint32_t max_len = 0;
     {
         std::vector<uint32_t> mx(nth, 0u);
@@ -2051,6 +2052,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     uint32_t mshift = 8;                         // smallest field that holds n (and the strike-out value above it)
     while ((1u << mshift) <= n) ++mshift;
 
+    phase("  counting sort");
     // sequences n .. 2n-1 are the reverse complements (nucleotides, both strands)
     const uint32_t nv = both ? 2 * n : n;
     HostVec<uint64_t> h_off(ctx, 2, (size_t)nv + 1);

@@ -141,7 +141,8 @@ void pgx_ctx_destroy(pgx_ctx *ctx) {
         if (a.first) (void)hipFree(a.first);
     for (auto &a : ctx->host_arena)
         if (a.first) (void)hipHostFree(a.first);
-    for (auto &a : ctx->host_scratch) std::free(a.first);
+    for (auto &a : ctx->host_scratch)
+        if (a.first) (void)hipHostFree(a.first);
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream);
     if (ctx->ev_main) (void)hipEventDestroy(ctx->ev_main);

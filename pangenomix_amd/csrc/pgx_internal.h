@@ -35,8 +35,9 @@ struct pgx_ctx {
     std::vector<std::pair<void *, size_t>> arena;
     // grow-only page-locked host staging buffers (slot -> buffer), same idea
     std::vector<std::pair<void *, size_t>> host_arena;
-    // grow-only pageable host scratch (slot -> buffer): the per-sequence arrays of a clustering call
-    // (tens of MB) are neither allocated, faulted in nor freed again by every call
+    // grow-only page-locked host scratch (slot -> buffer): the per-sequence arrays of a clustering call
+    // (tens of MB) are neither allocated, faulted in nor freed again by every call, and their copies to
+    // and from the device are asynchronous (from pageable memory every hipMemcpyAsync blocked the host)
     std::vector<std::pair<void *, size_t>> host_scratch;
 };
 
@@ -66,11 +67,12 @@ private:
         auto &a = ctx->host_scratch[(size_t)slot];
         const size_t bytes = count * sizeof(T) + 64;
         if (a.second < bytes) {
-            std::free(a.first);
+            if (a.first) (void)hipHostFree(a.first);
             a = {nullptr, 0};
             const size_t want = bytes + bytes / 4;
-            a.first = std::malloc(want);
-            if (a.first) a.second = want;
+            void *q = nullptr;
+            if (hipHostMalloc(&q, want, hipHostMallocDefault) == hipSuccess) a = {q, want};
+            else (void)hipGetLastError();
         }
         p = static_cast<T *>(a.first);
         n = p ? count : 0;
