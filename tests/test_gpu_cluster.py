@@ -7,7 +7,7 @@ import pytest
 
 import oracle
 from pangenomix_amd import pangenome, sparse_utils, synth
-from test_cluster_oracle import mutate, pack, params, rand_seq
+from test_cluster_oracle import AA as AA_LETTERS, mutate, pack, params, rand_seq
 
 pytestmark = pytest.mark.gpu
 
@@ -404,3 +404,61 @@ def test_errors_are_reported_and_leave_the_context_usable(gpu_ctx):
         gpu_ctx.cluster_greedy(res, off, sp)
     assert len(calls) == 2
     assert_same(gpu_ctx.cluster_greedy(*good, p), want)
+
+
+# ---- randomized sweep: family structure, parameters and window size drawn at random -----------------
+def _random_families(rng, alphabet, n_fam, max_members, lo, hi):
+    letters = list(alphabet)
+    seqs = []
+    for _ in range(n_fam):
+        L = int(rng.integers(lo, hi))
+        root = ''.join(rng.choice(letters, size=L))
+        seqs.append(root)
+        cur = root
+        for _ in range(int(rng.integers(0, max_members))):
+            src = list(cur if rng.random() < 0.4 else root)          # chains of variants and stars around the root
+            for p in rng.choice(len(src), size=int(rng.integers(0, max(1, len(src) * 35 // 100))), replace=False):
+                src[p] = letters[int(rng.integers(0, len(letters)))]
+            a, b = int(rng.integers(0, 6)), int(rng.integers(0, 6))   # ragged ends
+            cur = ''.join(src)[a:len(src) - b]
+            if len(cur) < 6:
+                cur = root
+            seqs.append(cur if alphabet != 'ACGT' or rng.random() < 0.7 else revcomp(cur))
+    seqs += [seqs[int(i)] for i in rng.integers(0, len(seqs), len(seqs) // 10)]   # exact duplicates
+    if alphabet == 'ACGT':
+        seqs += ['ACGTN' * 8, 'N' * 40]
+    else:
+        seqs += ['A' * 30, 'ACDEF', '']
+    order = rng.permutation(len(seqs))
+    return [seqs[i] for i in order]
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_randomized_protein_sets_match_oracle(seed, gpu_ctx):
+    rng = np.random.default_rng(1000 + seed)
+    c = float(rng.choice([0.7, 0.75, 0.8, 0.85, 0.9, 0.95, 0.97, 1.0]))
+    n = int(rng.choice([5, 5, 5, 4, 3, 2])) if c < 0.97 else 5
+    extra = {}
+    if rng.random() < 0.3:
+        extra['-b'] = int(rng.choice([5, 10, 32]))
+    if rng.random() < 0.3:
+        extra['-l'] = int(rng.choice([4, 20, 60]))
+    seqs = _random_families(rng, AA_LETTERS, int(rng.integers(5, 70)), int(rng.integers(1, 40)),
+                            int(rng.choice([12, 40, 120])), int(rng.choice([130, 400, 900])))
+    res, off = pack(seqs)
+    p = params(**{'-c': c, '-n': n}, **extra)
+    p.batch_size = int(rng.choice([0, 64, 128, 1024]))
+    assert_same(gpu_ctx.cluster_greedy(res, off, p), oracle.cluster_greedy(res, off, p))
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_randomized_nucleotide_sets_match_oracle(seed, gpu_ctx):
+    rng = np.random.default_rng(2000 + seed)
+    c = float(rng.choice([0.8, 0.85, 0.9, 0.95, 1.0]))
+    n = int(rng.choice([5, 6, 8, 10])) if c >= 0.9 else int(rng.choice([5, 6, 7]))
+    seqs = _random_families(rng, 'ACGT', int(rng.integers(4, 30)), int(rng.integers(1, 25)),
+                            int(rng.choice([20, 60])), int(rng.choice([150, 500])))
+    res, off = pack(seqs)
+    p = nt_params(**{'-c': c, '-n': n, '-r': int(rng.integers(0, 2))})
+    p.batch_size = int(rng.choice([0, 64, 256]))
+    assert_same_nt(gpu_ctx.cluster_greedy(res, off, p), oracle.cluster_greedy(res, off, p), 'seed %d' % seed)
