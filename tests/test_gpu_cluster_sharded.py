@@ -139,3 +139,23 @@ def test_bad_shard_arguments_are_rejected(gpu_ctx):
     p.shard_count, p.shard_index = 2, 2
     with pytest.raises(_native.PgxError):
         gpu_ctx.cluster_greedy(res, off, p)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_randomized_sets_on_virtual_ranks_match_oracle(seed):
+    """The randomized sets of test_gpu_cluster.py, split over 2 or 3 virtual ranks with small windows."""
+    from test_cluster_oracle import AA, pack
+    from test_gpu_cluster import _random_families
+    rng = np.random.default_rng(3000 + seed)
+    nucleotide = seed % 3 == 2
+    if nucleotide:
+        seqs = _random_families(rng, 'ACGT', int(rng.integers(4, 20)), int(rng.integers(1, 20)), 30, 300)
+        p = nt_params(**{'-c': float(rng.choice([0.8, 0.9])), '-n': int(rng.choice([5, 8]))})
+    else:
+        seqs = _random_families(rng, AA, int(rng.integers(10, 60)), int(rng.integers(1, 30)), 20, int(rng.choice([200, 600])))
+        p = params(**{'-c': float(rng.choice([0.7, 0.8, 0.9])), '-n': int(rng.choice([5, 4]))})
+    p.batch_size = int(rng.choice([64, 256, 1024]))
+    res, off = pack(seqs)
+    results = run_virtual_ranks(res, off, p, 2 + seed % 2)
+    assert_replicated(results)
+    (assert_same_nt if nucleotide else assert_same)(fold(results), oracle.cluster_greedy(res, off, p))
