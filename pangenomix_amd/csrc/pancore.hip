@@ -61,20 +61,6 @@ PanCoreGeom make_geom(uint32_t n_genes) {
     return g;
 }
 
-// Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic):
-// xor-1, xor-2 inside quads, half-row mirror, row mirror -> every lane holds its row-of-16
-// sum; row_bcast15 folds rows 0->1 and 2->3, row_bcast31 folds the lower half into rows 2,3;
-// lane 63 then holds the wave total.
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);  // row_half_mirror
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true);  // row_mirror
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);  // row_bcast15 -> rows 1,3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);  // row_bcast31 -> rows 2,3
-    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-}
-
 __device__ __forceinline__ uint32_t popc128(const uint4 &v) {
     return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
 }
@@ -102,7 +88,23 @@ __global__ __launch_bounds__(PC_WAVES * 64) void pan_core_sweep_kernel(
 
     uint4 acc_or = make_uint4(0u, 0u, 0u, 0u);
     uint4 acc_and = make_uint4(~0u, ~0u, ~0u, ~0u);
-    uint32_t parked = 0;
+    // The wave totals of 64 steps are formed TRANSPOSED: two steps' lane counts are merged into one register
+    // (lanes with the level's bit clear keep step a and add the partner lane's step-a count, the others keep
+    // step b), so that after levels 1..6 lane l holds the wave total of step l of the block -- 3 instructions
+    // per merge, 63 merges per 64 steps, instead of a 6-step DPP reduction + readlane + select per step
+    // (35 -> ~29 vector instructions per step; the kernel is VALU-bound).
+    auto merge = [&](uint32_t a, uint32_t b, uint32_t bit, auto partner) -> uint32_t {
+        const bool hi = (lane & bit) != 0u;
+        const uint32_t keep = hi ? b : a, give = hi ? a : b;
+        return keep + partner(give);
+    };
+    auto xor1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); };   // quad_perm [1,0,3,2]
+    auto xor2 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); };   // quad_perm [2,3,0,1]
+    auto xor4 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (4 << 10) | 0x1F); };
+    auto xor8 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); };  // row_ror:8
+    auto xor16 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1F); };
+    auto xor32 = [](uint32_t v) { return (uint32_t)__shfl_xor((int)v, 32); };
+    uint32_t p4 = 0, p5 = 0, p6 = 0;      // pending merges of the levels across chunks of 8 steps
 
     // The permutation is fetched 64 steps at a time with one coalesced vector load and
     // handed to the scalar unit with v_readlane (row base = SGPR pair, lane offset = VGPR).
@@ -133,19 +135,32 @@ __global__ __launch_bounds__(PC_WAVES * 64) void pan_core_sweep_kernel(
 #pragma unroll
         for (int u = 0; u < PC_UNROLL; ++u) nxt[u] = row_load(pv_cur, sub + u);
 
+        uint32_t cnt[PC_UNROLL];                 // steps >= S only reach lanes that are never stored
 #pragma unroll
         for (int u = 0; u < PC_UNROLL; ++u) {
-            const uint32_t j = c * PC_UNROLL + u;  // steps >= S only touch lanes that are never stored
             const uint4 row = cur[u];
             acc_or.x |= row.x; acc_or.y |= row.y; acc_or.z |= row.z; acc_or.w |= row.w;
             acc_and.x &= row.x; acc_and.y &= row.y; acc_and.z &= row.z; acc_and.w &= row.w;
             const uint32_t packed = popc128(acc_or) | (popc128(acc_and) << 16);
-            const uint32_t total = wave_sum_u32(active ? packed : 0u);
-            parked = (lane == (j & 63u)) ? total : parked;
+            cnt[u] = active ? packed : 0u;
         }
-        if ((c & (64u / PC_UNROLL - 1u)) == 64u / PC_UNROLL - 1u) {  // 64 totals parked: one coalesced store
-            const uint32_t jb = (c / (64u / PC_UNROLL)) * 64u;
-            if (jb + lane < S) out[jb + lane] = parked;
+        static_assert(PC_UNROLL == 8, "three merge levels inside a chunk");
+        const uint32_t m3 = merge(merge(merge(cnt[0], cnt[1], 1u, xor1), merge(cnt[2], cnt[3], 1u, xor1), 2u, xor2),
+                                  merge(merge(cnt[4], cnt[5], 1u, xor1), merge(cnt[6], cnt[7], 1u, xor1), 2u, xor2), 4u, xor4);
+        // lane l now holds, summed over its group of 8 lanes, the count of step 8 c + (l & 7)
+        if ((c & 1u) == 0u) p4 = m3;
+        else {
+            const uint32_t m4 = merge(p4, m3, 8u, xor8);
+            if ((c & 2u) == 0u) p5 = m4;
+            else {
+                const uint32_t m5 = merge(p5, m4, 16u, xor16);
+                if ((c & 4u) == 0u) p6 = m5;
+                else {   // 64 totals, lane l = step l of the block: one coalesced store
+                    const uint32_t m6 = merge(p6, m5, 32u, xor32);
+                    const uint32_t jb = (c / (64u / PC_UNROLL)) * 64u;
+                    if (jb + lane < S) out[jb + lane] = m6;
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < PC_UNROLL; ++u) cur[u] = nxt[u];
