@@ -646,38 +646,56 @@ int pgx_fasta_write_clustered(const pgx_fasta_set *S, const int32_t *cluster, co
 // generator), numpy's random_interval (smallest bit mask >= i, 32-bit draws, rejection) and the
 // Fisher-Yates order of RandomState.shuffle (i = n-1 .. 1, swap x[i] <-> x[j]). The caller passes the
 // generator's state (np.random.get_state(): key[624], pos) and stores the advanced state back.
-static inline uint32_t mt_next(uint32_t *mt, int32_t *pos) {
-    if (*pos >= 624) {
-        auto twist = [&](int k, int k1, int km) {
-            const uint32_t y = (mt[k] & 0x80000000u) | (mt[k1] & 0x7fffffffu);
-            mt[k] = mt[km] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
-        };
-        for (int k = 0; k < 227; ++k) twist(k, k + 1, k + 397);
-        for (int k = 227; k < 623; ++k) twist(k, k + 1, k - 227);
-        twist(623, 0, 396);
-        *pos = 0;
+// The loop runs over the DRAWS, not over the positions: every draw is masked, compared and applied as a swap
+// that is a no-op when the draw is rejected (x[i] <-> x[i]), and the position only advances on acceptance -- no
+// unpredictable branch per draw (the rejection loop mispredicts on a third of the draws). The generator's 624
+// outputs of a block are tempered in one vectorisable pass.
+static void mt_block(uint32_t *mt, uint32_t *out) {
+    auto twist = [&](int k, int k1, int km) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[k1] & 0x7fffffffu);
+        mt[k] = mt[km] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
+    };
+    for (int k = 0; k < 227; ++k) twist(k, k + 1, k + 397);
+    for (int k = 227; k < 623; ++k) twist(k, k + 1, k - 227);
+    twist(623, 0, 396);
+    for (int k = 0; k < 624; ++k) {
+        uint32_t y = mt[k];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        out[k] = y;
     }
-    uint32_t y = mt[(*pos)++];
-    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
-    return y;
 }
 int pgx_legacy_shuffles(uint32_t *key, int32_t *pos, uint32_t n, uint32_t n_iter, int32_t *out_perms) {
     if (!key || !pos || (n && n_iter && !out_perms) || *pos < 0 || *pos > 624) {
         pgx_set_error("pgx_legacy_shuffles: invalid argument");
         return PGX_ERR_INVALID;
     }
+    uint32_t buf[624];
+    int32_t p = *pos;
+    for (int k = p; k < 624; ++k) {     // what is left of the current block
+        uint32_t y = key[k];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        buf[k] = y;
+    }
     for (uint32_t it = 0; it < n_iter; ++it) {
         int32_t *x = out_perms + (size_t)it * n;
         for (uint32_t i = 0; i < n; ++i) x[i] = (int32_t)i;
-        for (uint32_t i = n; i-- > 1;) {
-            uint32_t mask = i;
-            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-            uint32_t j;
-            while ((j = mt_next(key, pos) & mask) > i) {
+        uint32_t i = n ? n - 1 : 0;
+        while (i >= 1) {
+            if (p >= 624) { mt_block(key, buf); p = 0; }
+            const int32_t stop = 624;
+            int32_t k = p;
+            for (; k < stop && i >= 1; ++k) {
+                const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(i);     // smallest bit mask >= i
+                const uint32_t j = buf[k] & mask;
+                const uint32_t acc = j <= i;
+                const uint32_t jj = acc ? j : i;
+                const int32_t t = x[i]; x[i] = x[jj]; x[jj] = t;
+                i -= acc;
             }
-            const int32_t t = x[i]; x[i] = x[j]; x[j] = t;
+            p = k;
         }
     }
+    *pos = p;
     return PGX_OK;
 }
 
