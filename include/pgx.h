@@ -283,6 +283,13 @@ int pgx_fasta_write_clustered(const pgx_fasta_set *fs, const int32_t *cluster, c
  * state out (np.random.get_state() / set_state()). out_perms: [n_iter][n] int32. */
 int pgx_legacy_shuffles(uint32_t *key, int32_t *pos, uint32_t n, uint32_t n_iter, int32_t *out_perms);
 
+/* pgx_legacy_shuffles + pgx_pan_core_coo in one call (pangenome_analysis.py:51-98 from the binary table's
+ * coordinates and the generator state): the draws are made on a host thread while the coordinates are uploaded and
+ * the bitmap is built. out_perms: [n_iter][n_genomes], the permutations that were used. */
+int pgx_pan_core_coo_rng(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, uint64_t n_records,
+                         uint32_t n_genes, uint32_t n_genomes, uint32_t *mt_key, int32_t *mt_pos, uint32_t n_iter,
+                         int32_t *out_perms, int32_t *out_pan, int32_t *out_core, uint64_t *out_duplicates);
+
 /* feature names (pangenome.py:1944-1969) as fixed-width zero-padded ASCII records (numpy 'S<width>'):
  * <prefix><cluster>[<variant><member>]; variant NULL = gene names */
 int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,

@@ -76,6 +76,8 @@ SIGNATURES = {
     'pgx_fasta_header_offsets': (_P, [_P]),
     'pgx_fasta_write_consolidated': (C.c_int, [_P, _S, _S, _S]),
     'pgx_legacy_shuffles': (C.c_int, [_P, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, _P]),
+    'pgx_pan_core_coo_rng': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_int32), C.c_uint32,
+                                      _P, _P, _P, C.POINTER(C.c_uint64)]),
     'pgx_format_labels': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_format_labels_ucs4': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_fasta_write_clustered': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _S, _S, _S, _S, _S]),
@@ -279,6 +281,22 @@ class Context(object):
         check(lib().pgx_pan_core_coo(self._h, _ptr(rows), _ptr(genomes), rows.size, int(n_genes), int(n_genomes),
                                      _ptr(perms), n_iter, _ptr(pan), _ptr(core), C.byref(dup)))
         return pan, core, int(dup.value)
+
+    def pan_core_coo_rng(self, rows, genomes, n_genes, n_genomes, n_iter, mt_key, mt_pos):
+        """(pan, core, duplicates, perms, new_pos): as pan_core_coo, with the permutations drawn by the library from the
+        legacy generator's state (`mt_key` uint32[624], advanced in place; `mt_pos`) beside the upload."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        genomes = np.ascontiguousarray(genomes, dtype=np.int32)
+        if rows.shape != genomes.shape or rows.ndim != 1:
+            raise ValueError('rows and genomes must be 1-D arrays of equal length')
+        perms = np.empty((int(n_iter), int(n_genomes)), dtype=np.int32)
+        pan = np.empty((int(n_iter), int(n_genomes)), dtype=np.int32)
+        core = np.empty((int(n_iter), int(n_genomes)), dtype=np.int32)
+        dup, pos = C.c_uint64(0), C.c_int32(int(mt_pos))
+        check(lib().pgx_pan_core_coo_rng(self._h, _ptr(rows), _ptr(genomes), rows.size, int(n_genes), int(n_genomes),
+                                         _ptr(mt_key), C.byref(pos), int(n_iter), _ptr(perms), _ptr(pan), _ptr(core),
+                                         C.byref(dup)))
+        return pan, core, int(dup.value), perms, int(pos.value)
 
     def pan_core(self, bits, n_genes, perms):
         perms = np.ascontiguousarray(perms, dtype=np.int32)

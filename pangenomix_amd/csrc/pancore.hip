@@ -31,6 +31,8 @@
 // (software-pipelined two deep: no change). DESIGN.md section 6.
 #include <algorithm>
 #include <cstdlib>
+#include <string>
+#include <thread>
 
 #include "pgx_internal.h"
 
@@ -389,6 +391,40 @@ int pgx_pan_core_coo(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, 
     if (rc != PGX_OK) return rc;
     if (n_iter && n_genomes) {
         rc = pan_core_from_device_bitmap(ctx, d_bits.as<uint64_t>(), n_genes, n_genomes, perms, n_iter, out_pan, out_core);
+        if (rc != PGX_OK) return rc;
+    }
+    uint64_t cnt[2] = {0, 0};
+    PGX_HIP(hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipStreamSynchronize(ctx->stream));
+    PGX_REQUIRE(cnt[1] == 0, "record with row or genome index out of range");
+    if (out_duplicates) *out_duplicates = cnt[0];
+    return PGX_OK;
+}
+
+// estimate_pan_core_size() in one call: the permutations are drawn from the legacy generator's state on a host
+// thread WHILE the coordinates travel to the device and the bitmap is built there (3 ms of draws beside 2-3 ms of
+// copies for the 150,000 x 400 table), then they follow and the curves are computed.
+int pgx_pan_core_coo_rng(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, uint64_t n_records,
+                         uint32_t n_genes, uint32_t n_genomes, uint32_t *mt_key, int32_t *mt_pos, uint32_t n_iter,
+                         int32_t *out_perms, int32_t *out_pan, int32_t *out_core, uint64_t *out_duplicates) {
+    PGX_REQUIRE(ctx, "NULL context");
+    PGX_REQUIRE(n_records == 0 || (rows && genomes), "NULL record arrays");
+    PGX_REQUIRE(mt_key && mt_pos, "NULL generator state");
+    PGX_REQUIRE(n_iter == 0 || n_genomes == 0 || (out_perms && out_pan && out_core), "NULL argument");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    int rc_draw = PGX_OK;
+    std::string draw_error;
+    std::thread draw([&]() {
+        rc_draw = pgx_legacy_shuffles(mt_key, mt_pos, n_genomes, n_iter, out_perms);
+        if (rc_draw != PGX_OK) draw_error = pgx_last_error();     // (the error text is thread-local)
+    });
+    PcBuf d_bits(ctx, PC_SLOT_BITS), d_cnt(ctx, PC_SLOT_CNT);
+    int rc = upload_and_build_bitmap(ctx, rows, genomes, n_records, n_genes, n_genomes, d_bits, d_cnt);
+    draw.join();
+    if (rc != PGX_OK) return rc;
+    if (rc_draw != PGX_OK) { pgx_set_error("%s", draw_error.c_str()); return rc_draw; }
+    if (n_iter && n_genomes) {
+        rc = pan_core_from_device_bitmap(ctx, d_bits.as<uint64_t>(), n_genes, n_genomes, out_perms, n_iter, out_pan, out_core);
         if (rc != PGX_OK) return rc;
     }
     uint64_t cnt[2] = {0, 0};
