@@ -663,15 +663,17 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
     if ((PASS2 || redo) && M.complete) { slab(M.code, M.mult, lane < M.n); FT_LAP(ft, 6); return; }
     uint32_t pc = 0u, pm = 0u, np = 0u;
     bool flushed = false;
-    for (uint32_t base = 0; base < nw; base += 512u) {
-        uint32_t c[8], m[8], nbw[8];
+    for (uint32_t base = 0; base < nw; base += 256u) {
+        uint32_t c[4], m[4], nbw[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) load_word(base + 64u * j, c[j], m[j]);
+        for (int j = 0; j < 4; ++j) load_word(base + 64u * j, c[j], m[j]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { nbw[j] = 0u; if (m[j]) nbw[j] = A.newbits[c[j] >> 5]; }
-        if (!PASS2) { if (__ballot(nbw[0] == 0x12345u && nbw[7] == 0x54321u) == ~0ull) return; FT_LAP(ft, 1); }   // (waits for the probes)
+        for (int j = 0; j < 4; ++j) { nbw[j] = 0u; if (m[j]) nbw[j] = A.newbits[c[j] >> 5]; }
+#ifdef PGX_FTIME
+        if (!PASS2) { if (__ballot(nbw[0] == 0x12345u && nbw[3] == 0x54321u) == ~0ull) return; FT_LAP(ft, 1); }   // (waits for the probes)
+#endif
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             if (base + 64u * j >= nw) break;
             const bool live = (nbw[j] >> (c[j] & 31u)) & 1u;
             const unsigned long long mask = __ballot(live);
@@ -759,8 +761,10 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         uint32_t visits = 0;
         bool hot = false, full = false;
         Marked marked{0u, 0u, 0u, false};
+#ifdef PGX_FTIME
         if (__ballot(nw == 0xFFFFFFFFu && thr == 0u) == ~0ull) return;   // (consumes the prologue loads)
         FT_LAP(ft, 0);
+#endif
         filter_walk<NEWONLY, false, FH>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full, marked, ft);
         wave_lds_sync();
         for (int d = 32; d > 0; d >>= 1) visits += __shfl_xor(visits, d);
