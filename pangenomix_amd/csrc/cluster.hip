@@ -2161,12 +2161,14 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_lines, d_pool[2], d_idx,
         d_newbits, d_touched, d_first, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
-        d_ulist, d_new_list, d_flags, d_gscratch, d_order, d_list, d_gather, d_pk, d_pkoff;
+        d_ulist, d_new_list, d_flags, d_gscratch, d_order, d_list, d_gather, d_pk, d_pkoff,
+        d_counters2, d_best2, d_flags2, d_pairsW2, d_gscratch2;   // second set of a window's own state (see `overlap`)
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_lines,
                          &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_best_own, &d_rcvis,
                          &d_counters, &d_visits, &d_pairsW, &d_pairsK, &d_blk_list, &d_ulist, &d_new_list, &d_flags,
-                         &d_gscratch, &d_order, &d_list, &d_gather, &d_pk, &d_pkoff};
+                         &d_gscratch, &d_order, &d_list, &d_gather, &d_pk, &d_pkoff,
+                         &d_counters2, &d_best2, &d_flags2, &d_pairsW2, &d_gscratch2};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -2206,18 +2208,33 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_pairsW.alloc((size_t)pair_cap * sizeof(Pair)));
     PGX_HIP(d_pairsK.alloc((size_t)pair_cap_k * sizeof(Pair)));
     if (need_gscratch) PGX_HIP(d_gscratch.alloc((size_t)diag_grid * gs_stride * 4));
+    // Consecutive windows overlap on two streams (proteins, one process): the tail of window w -- the pass over
+    // all members after its last block, that pass's diagonal tests and alignments, the close -- only READS the
+    // index, and so does phase A of window w+1. Each window therefore has its own counters, best keys, member flags,
+    // pair records and host copies (two sets, used alternately); window w+1 starts when the index of window w is
+    // final (event after its last strike-out) and appends to the index only after window w's close (second event).
+    // A few hundred pairs per evaluation keep a 60-us dependent chain per alignment on the path otherwise.
+    const bool overlap = !nt && !P->exchange && !std::getenv("PGX_NO_OVERLAP");
+    if (overlap) {
+        PGX_HIP(d_counters2.alloc(C_COUNT * 4));
+        PGX_HIP(hipMemsetAsync(d_counters2.p, 0, C_COUNT * 4, st));
+        PGX_HIP(d_best2.alloc((size_t)window_cap * 8));
+        PGX_HIP(d_flags2.alloc(4 * (size_t)window_cap));
+        PGX_HIP(d_pairsW2.alloc((size_t)pair_cap * sizeof(Pair)));
+        if (need_gscratch) PGX_HIP(d_gscratch2.alloc((size_t)diag_grid * gs_stride * 4));
+    }
     // overflow pool of the index: sized before every window from the entries that exist and the most the
     // window can add (every array is re-allocated with twice the need: <= 8 words per entry in all)
     int pool_cur = 0;
     uint64_t pool_cap = 0;
-    auto ensure_pool = [&](uint64_t entries) -> int {
+    auto ensure_pool = [&](uint64_t entries, hipStream_t on) -> int {
         const uint64_t need = 8 * entries + 4096;
         if (need <= pool_cap) return PGX_OK;
         if (need > 0xFFFFFFF0ull) { pgx_set_error("pgx_cluster_greedy: word index too large for 32-bit pool offsets"); return PGX_ERR_CAPACITY; }
         const uint64_t want = std::min<uint64_t>(0xFFFFFFF0ull, need + need / 2);
         DevBuf &nb_ = d_pool[pool_cur ^ 1];
         PGX_HIP(nb_.alloc(want * 4));
-        if (pool_cap) PGX_HIP(hipMemcpyAsync(nb_.p, d_pool[pool_cur].p, pool_cap * 4, hipMemcpyDeviceToDevice, st));
+        if (pool_cap) PGX_HIP(hipMemcpyAsync(nb_.p, d_pool[pool_cur].p, pool_cap * 4, hipMemcpyDeviceToDevice, on));
         pool_cur ^= 1;
         pool_cap = want;
         return PGX_OK;
@@ -2294,7 +2311,23 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(h_new.reserve(window_cap)); PGX_HIP(hK.reserve(pair_cap_k)); PGX_HIP(hW.reserve(kPrefix));
     PGX_HIP(h_rcvis.reserve(window_cap)); PGX_HIP(h_push.reserve(2 * (size_t)window_cap + 4 * kBlockCap));
     PGX_HIP(h_list.reserve(pair_cap_k)); PGX_HIP(h_gather.reserve(pair_cap_k));
-    uint32_t *dc = d_counters.as<uint32_t>();
+    // what a window's CLOSE publishes has its own host buffers, one set per window in flight
+    Pinned<Pair> hW2;
+    Pinned<unsigned long long> h_best2;
+    Pinned<uint32_t> h_ccnt, h_ccnt2;
+    hW2.bind(ctx, 10); h_best2.bind(ctx, 11); h_ccnt.bind(ctx, 12); h_ccnt2.bind(ctx, 13);
+    PGX_HIP(h_ccnt.reserve(C_COUNT));
+    if (overlap) { PGX_HIP(hW2.reserve(kPrefix)); PGX_HIP(h_best2.reserve(window_cap)); PGX_HIP(h_ccnt2.reserve(C_COUNT)); }
+    struct Events {   // (destroyed on every way out)
+        hipEvent_t strike[2] = {nullptr, nullptr}, post[2] = {nullptr, nullptr};
+        ~Events() { for (hipEvent_t e : strike) if (e) (void)hipEventDestroy(e); for (hipEvent_t e : post) if (e) (void)hipEventDestroy(e); }
+    } ev;
+    for (int i = 0; i < 2; ++i) {
+        PGX_HIP(hipEventCreateWithFlags(&ev.strike[i], hipEventDisableTiming));
+        PGX_HIP(hipEventCreateWithFlags(&ev.post[i], hipEventDisableTiming));
+    }
+    const hipStream_t st_main = st;
+    uint32_t *const dc_set[2] = {d_counters.as<uint32_t>(), d_counters2.as<uint32_t>()};
     unsigned long long *d_rcvis_p = d_rcvis.as<unsigned long long>();
     // record-sharded mode (see pgx.h): this process filters and aligns the window members ql % shard_count ==
     // shard_index; the window's best keys live in the caller's exchange buffer and are all-gathered after
@@ -2305,8 +2338,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     const uint32_t shard_index = P->shard_count > 0 ? (uint32_t)P->shard_index : 0u;
     const bool count_replicated = shard_index == 0;  // work every process repeats is counted by the first one only
     uint64_t visits_rc = 0;
-    uint8_t *d_done = d_flags.as<uint8_t>(), *d_inblk = d_done + window_cap;
-    uint8_t *d_hascand = d_done + 2 * (size_t)window_cap, *d_accepted = d_done + 3 * (size_t)window_cap;
+    unsigned long long *const d_best_set[2] = {d_best, d_best2.as<unsigned long long>()};
+    uint8_t *const d_flags_set[2] = {d_flags.as<uint8_t>(), d_flags2.as<uint8_t>()};
     std::vector<uint8_t> status(window_cap);
     HostVec<uint8_t> strand_of(ctx, 11, n, (uint8_t)0);
     PGX_REQUIRE(strand_of.ok(), "out of host memory");
@@ -2342,11 +2375,25 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     Chunks chunks;
     for (uint32_t b0 = 0, nb; b0 < n; b0 += nb) {
         nb = form_window(b0, chunks);                      // queries of this window
+        // this window's own state and stream (see `overlap`); the names below shadow the first set's
+        const int set = overlap ? (int)(S.sweeps & 1u) : 0;
+        const hipStream_t st = set ? ctx->stream2 : st_main;
+        uint32_t *const dc = dc_set[set];
+        unsigned long long *const d_best = d_best_set[set];
+        uint8_t *const d_done = d_flags_set[set], *const d_inblk = d_done + window_cap;
+        uint8_t *const d_hascand = d_done + 2 * (size_t)window_cap, *const d_accepted = d_done + 3 * (size_t)window_cap;
+        Pinned<Pair> &hW_w = set ? hW2 : hW;
+        Pinned<unsigned long long> &h_best_w = set ? h_best2 : h_best;
+        Pinned<uint32_t> &h_ccnt_w = set ? h_ccnt2 : h_ccnt;
+        uint32_t *const d_gs = (set ? d_gscratch2 : d_gscratch).as<uint32_t>();
+        if (overlap && S.sweeps > 0)   // the index of the window before is final (its last strike-out is done)
+            PGX_HIP(hipStreamWaitEvent(st, ev.strike[set ^ 1], 0));
+        bool strike_recorded = false;
         const uint32_t ns = both ? 2 * nb : nb;            // window slots: + one per reverse complement
         const uint32_t n_reps = (uint32_t)rep_seq.size();
         const uint64_t window_words = h_off[b0 + nb] - h_off[b0];
         // (the bookkeeping of the window before may still be pending: its members count as representatives)
-        { int rc = ensure_pool(S.rep_words + pending_words + window_words); if (rc) return rc; }
+        { int rc = ensure_pool(S.rep_words + pending_words + window_words, st); if (rc) return rc; }
         uint32_t *d_poolp = d_pool[pool_cur].as<uint32_t>();
         if (nt) {  // at cd-hit-est's -n 5 -c 0.8 one shared word is enough: size the pair buffer for all pairs
             const uint64_t need = (uint64_t)ns * ((uint64_t)n_reps + nb) + 1024;
@@ -2369,7 +2416,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // window cannot use the 16-lane fast path: query length + longest sequence, or the band
         // LDS slot per pair of the 16-lane aligner: sized for two sequences as long as the window's longest query
         const int a16_slot = 2 * (int)h_len[b0] <= 1024 - 96 ? 1024 : (2 * (int)h_len[b0] <= 2048 - 96 ? 2048 : kA16MaxSlot);
-        Pair *pairsW = d_pairsW.as<Pair>();
+        Pair *pairsW = (set ? d_pairsW2 : d_pairsW).as<Pair>();
         FilterArgs FA{};
         FA.lines = d_lines.as<IndexLine>(); FA.pool = d_poolp; FA.newbits = d_newbits.as<uint32_t>();
         FA.d_round_lo = dc + C_SEG0; FA.d_round_hi = dc + C_NEW; FA.epoch = 0;
@@ -2389,7 +2436,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 ProfScope prof(ctx, "diag_kernel", st);
                 auto kern = h_len[b0] <= kDiagLdsSmall ? diag_kernel<kDiagLdsSmall> : diag_kernel<kDiagLdsCap>;
                 kern<<<dg, 64, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
-                                        P->band_width, P->identity, d_gscratch.as<uint32_t>(), gs_stride, dc + C_WIDE);
+                                        P->band_width, P->identity, d_gs, gs_stride, dc + C_WIDE);
             }
             LAUNCH_CHECK();
             {
@@ -2468,6 +2515,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // index, and the pass against them assigns most of the remaining members; a second round confirms
         // the members the first round's representatives rejected (the outliers of their families). All on
         // the device: the host learns the outcome with the first block's results.
+        if (overlap && S.sweeps > 1)   // from here on the index is written: the window before must have closed
+            PGX_HIP(hipStreamWaitEvent(st, ev.post[set ^ 1], 0));
         static const int n_disc = std::getenv("PGX_ROUNDS") ? std::atoi(std::getenv("PGX_ROUNDS")) : kDiscoveryRounds;
         for (int round = 0; round < n_disc; ++round) {
             if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)tag_stride * n_codes * 4, st)); epoch_tag = 1; }
@@ -2583,7 +2632,10 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 block_cap = std::max(kBlockCapMin, block_cap / 4);
                 continue;
             }
-            if (n_blk == 0) break;
+            if (n_blk == 0) {
+                if (overlap) { PGX_HIP(hipEventRecord(ev.strike[set], st)); strike_recorded = true; }   // nothing tentative is left
+                break;
+            }
             // resolve the block in order: first accepted in-block representative by (minc, index)
             const auto t_r0 = std::chrono::steady_clock::now();
             ++n_blocks;
@@ -2692,6 +2744,10 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, 1u);
                 block_begin_kernel<<<1, 1, 0, st>>>(dc);
                 LAUNCH_CHECK();
+                if (overlap && n_open == n_blk) {   // the last block: from here on this window only reads the index
+                    PGX_HIP(hipEventRecord(ev.strike[set], st));
+                    strike_recorded = true;
+                }
                 int rc = filter_new_and_evaluate(dc + C_ZERO, dc + C_BLK);
                 if (rc) return rc;
             }
@@ -2700,43 +2756,62 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // ---- close the window ---------------------------------------------------------------
         {   // counters, winners, and exactly the pair records that exist, in one launch
             PubArgs pa{};
-            pa.seg[0] = {dc, h_cnt.p, nullptr, C_COUNT, 1, C_COUNT};
-            pa.seg[1] = {reinterpret_cast<const uint32_t *>(d_best), reinterpret_cast<uint32_t *>(h_best.p), nullptr, nb, 2, nb};
-            pa.seg[2] = {reinterpret_cast<const uint32_t *>(pairsW), reinterpret_cast<uint32_t *>(hW.p), dc + C_NW, 0, kPairWords,
-                         (uint32_t)std::min<size_t>(hW.cap, pair_cap)};
+            pa.seg[0] = {dc, h_ccnt_w.p, nullptr, C_COUNT, 1, C_COUNT};
+            pa.seg[1] = {reinterpret_cast<const uint32_t *>(d_best), reinterpret_cast<uint32_t *>(h_best_w.p), nullptr, nb, 2, nb};
+            pa.seg[2] = {reinterpret_cast<const uint32_t *>(pairsW), reinterpret_cast<uint32_t *>(hW_w.p), dc + C_NW, 0, kPairWords,
+                         (uint32_t)std::min<size_t>(hW_w.cap, pair_cap)};
             pa.n = 3;
             if (both) pa.seg[pa.n++] = {reinterpret_cast<const uint32_t *>(d_rcvis_p), reinterpret_cast<uint32_t *>(h_rcvis.p), nullptr, nb, 2, nb};
+            if (overlap && !strike_recorded) PGX_HIP(hipEventRecord(ev.strike[set], st));
             publish_kernel<<<64, 256, 0, st>>>(pa);
             LAUNCH_CHECK();
+            if (overlap) PGX_HIP(hipEventRecord(ev.post[set], st));
         }
-        PGX_HIP(spin_sync(st));
-        const uint32_t nW = h_cnt.p[C_NW];
-        if (h_cnt.p[C_ERR]) {
-            pgx_set_error("pgx_cluster_greedy: word index failure %u in the window at %u", h_cnt.p[C_ERR], b0);
-            return PGX_ERR_CAPACITY;
-        }
-        if (nW > pair_cap) {
-            pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u > %u) in the window at %u", nW, pair_cap, b0);
-            return PGX_ERR_CAPACITY;
-        }
-        if (nW > hW.cap) {  // the host buffer was too small: grow it and fetch again
-            PGX_HIP(hW.reserve(nW));  // (reserve keeps nothing: copy the whole range again)
-            PGX_HIP(hipMemcpyAsync(hW.p, pairsW, (size_t)nW * sizeof(Pair), hipMemcpyDeviceToHost, st));
-            PGX_HIP(spin_sync(st));
-        }
+        // What the close published is looked at by the window's bookkeeping, which waits for it first: with
+        // overlapping windows that is when the next window's first kernels have been enqueued, without right here.
+        auto closed = [&, b0, st, pairsW, ev_post = ev.post[set], p_cnt = &h_ccnt_w, p_hW = &hW_w](uint32_t &nW) -> int {
+            if (overlap) {
+                const auto t0 = std::chrono::steady_clock::now();
+                hipError_t e;
+                while ((e = hipEventQuery(ev_post)) == hipErrorNotReady) {
+                }
+                g_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                PGX_HIP(e);
+            } else {
+                PGX_HIP(spin_sync(st));
+            }
+            nW = p_cnt->p[C_NW];
+            if (p_cnt->p[C_ERR]) {
+                pgx_set_error("pgx_cluster_greedy: word index failure %u in the window at %u", p_cnt->p[C_ERR], b0);
+                return PGX_ERR_CAPACITY;
+            }
+            if (nW > pair_cap) {
+                pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u > %u) in the window at %u", nW, pair_cap, b0);
+                return PGX_ERR_CAPACITY;
+            }
+            if (nW > p_hW->cap) {  // the host buffer was too small: grow it and fetch again (the window's stream is idle by now)
+                PGX_HIP(p_hW->reserve(nW));  // (reserve keeps nothing: copy the whole range again)
+                PGX_HIP(hipMemcpyAsync(p_hW->p, pairsW, (size_t)nW * sizeof(Pair), hipMemcpyDeviceToHost, st));
+                PGX_HIP(spin_sync(st));
+            }
+            return PGX_OK;
+        };
+        uint32_t nW = 0;
+        if (!overlap) { int rc = closed(nW); if (rc) return rc; }
         // The window's bookkeeping -- winners, numbering of the new representatives, identities, the candidates
         // the one-by-one pass would have examined -- works on the host copies only: it is deferred until the
         // next window's first kernels are enqueued (the device starts the next window right away).
         const auto t_c0 = std::chrono::steady_clock::now();
         {
-            const Pair *pW = hW.p;
             pending_words = window_words;
-            deferred = [&, b0, nb, nW, pW]() -> int {
+            deferred = [&, b0, nb, nW, closed, p_best = &h_best_w, p_hW = &hW_w]() mutable -> int {
+                if (overlap) { int rc = closed(nW); if (rc) return rc; }
+                const Pair *pW = p_hW->p;
                 pending_words = 0;
                 // members that were never in a block: their winner is the 64-bit minimum in best[]
                 for (uint32_t q = 0; q < nb; ++q) {
                     if (status[q] != ST_OPEN) continue;
-                    const unsigned long long key = h_best.p[q];
+                    const unsigned long long key = p_best->p[q];
                     if (key == kNoBest) { pgx_set_error("pgx_cluster_greedy: unresolved member after the last block"); return PGX_ERR_INTERNAL; }
                     status[q] = ST_MEMBER;
                     winner_key[q] = key;
@@ -2813,6 +2888,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         fprintf(stderr, "[ftime] %llu waves, %.0f clocks per wave; direct %llu, fallbacks %llu, classic %llu\n", h[12], tot / (double)h[12], h[13], h[14], h[15]);
     }
 #endif
+    if (overlap) PGX_HIP(hipStreamSynchronize(ctx->stream2));
     unsigned long long visits_table = 0;
     PGX_HIP(hipMemcpyAsync(&visits_table, d_visits.p, 8, hipMemcpyDeviceToHost, st));
     PGX_HIP(hipStreamSynchronize(st));

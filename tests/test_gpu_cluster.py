@@ -462,3 +462,19 @@ def test_randomized_nucleotide_sets_match_oracle(seed, gpu_ctx):
     p = nt_params(**{'-c': c, '-n': n, '-r': int(rng.integers(0, 2))})
     p.batch_size = int(rng.choice([0, 64, 256]))
     assert_same_nt(gpu_ctx.cluster_greedy(res, off, p), oracle.cluster_greedy(res, off, p), 'seed %d' % seed)
+
+
+@pytest.mark.parametrize('window', [64, 1024])
+def test_overlapped_windows_match_the_serial_loop(window, gpu_ctx, monkeypatch):
+    """Consecutive windows overlap on two streams (each with its own counters, best keys, flags and pair records);
+    the result must not depend on it: the same call with PGX_NO_OVERLAP=1 and the oracle give the same everything,
+    run after run, with hundreds of small windows in flight."""
+    res, off, _ = synth.ProteinSet(40, 1500, 4000, 600, 91).nr_arrays()      # 41 k sequences, 5.5 k clusters
+    p = params()
+    p.batch_size = window
+    want = oracle.cluster_greedy(res, off, p)
+    monkeypatch.setenv('PGX_NO_OVERLAP', '1')
+    assert_same(gpu_ctx.cluster_greedy(res, off, p), want)
+    monkeypatch.delenv('PGX_NO_OVERLAP')
+    for _ in range(3):
+        assert_same(gpu_ctx.cluster_greedy(res, off, p), want)
