@@ -304,6 +304,9 @@ def main():
                     'frac': dom_gbs / HBM_PEAK_GBS, 'traffic': traffic(*fam[dom]), 'traffic_source': pmc_src,
                     'avg_kernel_ms': dom_ms / dom_n, 'launches_per_step': dom_n,
                     'algorithmic_bytes_per_launch': alg / dom_n,
+                    'note': 'kernel durations as they are in the timed configuration: consecutive windows overlap on two '
+                            'streams, so a launch shares the device with the other window\'s (PGX_NO_OVERLAP=1 gives '
+                            'exclusive durations: DESIGN.md section 6)',
                     'model': {'filter_kernel': '4 B x P posting visits of the sequential rule (SURVEY 8d)',
                               'align_kernel': 'ceil(5 A / 8): residues of the aligned representatives (SURVEY 8d)',
                               'diag_kernel': 'ceil(5 A / 8) (SURVEY 8d has no term of its own for the diagonal test)'}[dom],
