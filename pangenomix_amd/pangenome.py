@@ -521,6 +521,29 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
 # ---------------------------------------------------------------------------
 # entry points (reference :44-156, :159-316)
 # ---------------------------------------------------------------------------
+def _save_both(df_alleles, allele_npz, df_genes, gene_npz):
+    """The two tables of a pangenome, written side by side (the deflate of the .npz members releases the GIL);
+    the messages come in the reference's order."""
+    import threading
+    print('Saving', allele_npz, '...')
+    errors = []
+
+    def save_genes():
+        try:
+            df_genes.to_npz(gene_npz)
+        except BaseException as exc:      # re-raised by the caller's thread
+            errors.append(exc)
+    t = threading.Thread(target=save_genes)
+    t.start()
+    try:
+        df_alleles.to_npz(allele_npz)
+    finally:
+        print('Saving', gene_npz, '...')
+        t.join()
+    if errors:
+        raise errors[0]
+
+
 def _check_format(output_format):
     if output_format not in {'lsdf', 'sparr'}:
         print('Unrecognized output format, switching to lsdf')
@@ -562,10 +585,7 @@ def build_cds_pangenome(genome_faa_paths, output_dir, name='Test',
 
     allele_npz = _p(output_dir, name, '_strain_by_allele') + '.npz'
     gene_npz = _p(output_dir, name, '_strain_by_gene') + '.npz'
-    print('Saving', allele_npz, '...')
-    df_alleles.to_npz(allele_npz)
-    print('Saving', gene_npz, '...')
-    df_genes.to_npz(gene_npz)
+    _save_both(df_alleles, allele_npz, df_genes, gene_npz)
     return df_alleles, df_genes
 
 
@@ -620,10 +640,7 @@ def build_noncoding_pangenome(genome_data, output_dir, name='Test', flanking=(0,
 
     allele_npz = _p(output_dir, name, '_strain_by_noncoding_allele') + '.npz'
     gene_npz = _p(output_dir, name, '_strain_by_noncoding_gene') + '.npz'
-    print('Saving', allele_npz, '...')
-    df_alleles.to_npz(allele_npz)
-    print('Saving', gene_npz, '...')
-    df_genes.to_npz(gene_npz)
+    _save_both(df_alleles, allele_npz, df_genes, gene_npz)
     return df_alleles, df_genes
 
 # ---------------------------------------------------------------------------
