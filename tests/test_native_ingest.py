@@ -227,3 +227,19 @@ def test_lex_key_orders_like_the_names():
     names = ['N_C%dA%d' % cm for cm in zip(c, m)]
     order = np.lexsort((pg._lex_key(m, True), pg._lex_key(c, False)))
     assert [names[i] for i in order] == sorted(names)
+
+
+def test_format_labels_matches_python_formatting():
+    """Feature names from the library (numpy 'U' records written by several threads; the 'S' path for a
+    prefix that is not ASCII) equal the reference's string formatting (pangenome.py:1944-1969)."""
+    from pangenomix_amd import _native
+    rng = np.random.default_rng(4)
+    c = np.concatenate([rng.integers(0, 2_000_000, 70000), [0, 9, 10, 99, 100, 1999999]]).astype(np.int32)
+    m = np.concatenate([rng.integers(0, 500, 70000), [0, 9, 10, 99, 100, 499]]).astype(np.int32)
+    for prefix in ('Test_C', 'Étude_C'):
+        alleles = _native.format_labels(prefix, c, m, 'A')
+        genes = _native.format_labels(prefix, c)
+        assert alleles.dtype.kind == 'U' and genes.dtype.kind == 'U'
+        assert alleles.tolist() == ['%s%dA%d' % (prefix, a, b) for a, b in zip(c.tolist(), m.tolist())]
+        assert genes.tolist() == ['%s%d' % (prefix, a) for a in c.tolist()]
+    assert _native.format_labels('X', np.zeros(0, dtype=np.int32)).shape == (0,)
