@@ -2371,6 +2371,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     uint64_t n_blocks = 0;
     g_wait_s = 0.0;
     std::function<int()> deferred;  // bookkeeping of the window before, see the close of a window
+    std::vector<uint32_t> members;  // cluster -> members numbered so far
     uint64_t pending_words = 0;     // ... and its words
     Chunks chunks;
     for (uint32_t b0 = 0, nb; b0 < n; b0 += nb) {
@@ -2852,6 +2853,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                     pgx_set_error("pgx_cluster_greedy: alignment band wider than %d diagonals", kMaxBand);
                     return PGX_ERR_CAPACITY;
                 }
+                // the window's outputs, in the caller's order; member numbers follow the sorted order (A.3)
+                members.resize(rep_seq.size(), 0u);
+                for (uint32_t q = 0; q < nb; ++q) {
+                    const uint32_t k = b0 + q, o = order[k];
+                    const int32_t c = cluster_of[k];
+                    out_cluster[o] = c;
+                    out_member[o] = (int32_t)members[(size_t)c]++;
+                    out_identity[o] = iden_of[k] >= 0 ? (float)iden_of[k] / (float)h_len[k] : 0.f;
+                    if (out_strand) out_strand[o] = strand_of[k];   // (set for members only)
+                }
                 return PGX_OK;
             };
         }
@@ -2898,21 +2909,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     S.n_clusters = rep_seq.size();
 
     phase("window loop");
-    // ---- outputs in the caller's order; member numbers follow the sorted order (A.3) ------
-    std::vector<uint32_t> members(rep_seq.size(), 0);
-    HostVec<uint32_t> member_no(ctx, 12, n);
-    PGX_REQUIRE(member_no.ok(), "out of host memory");
-    for (uint32_t k = 0; k < n; ++k) member_no[k] = members[cluster_of[k]]++;   // (in sorted order)
-    parallel_for(n, nth, [&](unsigned, size_t b, size_t e) {
-        for (size_t k = b; k < e; ++k) {
-            const uint32_t o = order[k];
-            out_cluster[o] = cluster_of[k];
-            out_member[o] = (int32_t)member_no[k];
-            out_identity[o] = iden_of[k] >= 0 ? (float)iden_of[k] / (float)h_len[k] : 0.f;
-            if (out_strand) out_strand[o] = strand_of[k];   // (set for members only)
-        }
-    });
-    phase("outputs");
+    // (the outputs were written window by window, with each window's bookkeeping)
     if (out_n_clusters) *out_n_clusters = (uint32_t)rep_seq.size();
     if (stats) *stats = S;
     return PGX_OK;
