@@ -1079,6 +1079,17 @@ __global__ __launch_bounds__(256) void certain_kernel(DevSeqs S, const uint32_t 
     }
 }
 
+// per-sequence thresholds from the per-length tables tab[0..n_len) = aa1, [n_len..2 n_len) = aas, [2 n_len..) = aan
+__global__ __launch_bounds__(256) void thresholds_kernel(const uint32_t *__restrict__ len, uint32_t n,
+                                                        const int32_t *__restrict__ tab, uint32_t n_len,
+                                                        int32_t *__restrict__ aa1, int32_t *__restrict__ aas,
+                                                        int32_t *__restrict__ aan) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t L = len[k];
+    aa1[k] = tab[L]; aas[k] = tab[n_len + L]; aan[k] = tab[2 * n_len + L];
+}
+
 // (hipMemsetAsync between kernels left the stream idle for ~130 us each time -- 55 ms per run in the
 // first timeline of this design -- so the per-round clears are launches of our own)
 __global__ __launch_bounds__(256) void zero_kernel(uint4 *__restrict__ p, size_t n16) {
@@ -2087,24 +2098,28 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     });
     phase("lengths + order");
     // per-query thresholds in double, exactly as the sequential rule computes them
-    HostVec<int32_t> h_aa1(ctx, 5, n), h_aas(ctx, 6, n), h_aan(ctx, 7, n);
-    PGX_REQUIRE(h_aa1.ok() && h_aas.ok() && h_aan.ok(), "out of host memory");
+    // They depend on the length only: one small table per threshold (host, in double), expanded per sequence on
+    // the device (thresholds_kernel) instead of three host passes and three uploads of n integers.
+    HostVec<int32_t> h_thr(ctx, 5, 3 * ((size_t)max_len + 1));
+    PGX_REQUIRE(h_thr.ok(), "out of host memory");
     {
-        std::vector<uint8_t> bad(nth, 0);
-        parallel_for(n, nth, [&](unsigned t, size_t b, size_t e) {
-            for (size_t k = b; k < e; ++k) {
-                const int len = (int)h_len[k];
-                const int aa1 = (int)(P->identity * (double)len);
-                h_aa1[k] = aa1;
-                if (P->identity > 0.95) {
-                    h_aas[k] = len - (nt ? 4 : 2) + 1 - (len - aa1) * (nt ? 4 : 2);
-                    h_aan[k] = len - P->word_len + 1 - (len - aa1) * P->word_len;
-                } else {
-                    h_aas[k] = (int)(P->aas_cutoff * (double)len);
-                    h_aan[k] = (int)(P->aan_cutoff * (double)len);
-                }
-                if (h_aas[k] < 1) bad[t] = 1;
+        int32_t *t_aa1 = h_thr.data(), *t_aas = t_aa1 + max_len + 1, *t_aan = t_aas + max_len + 1;
+        for (uint32_t L = 0; L <= max_len; ++L) {
+            const int len = (int)L;
+            const int aa1 = (int)(P->identity * (double)len);
+            t_aa1[L] = aa1;
+            if (P->identity > 0.95) {
+                t_aas[L] = len - (nt ? 4 : 2) + 1 - (len - aa1) * (nt ? 4 : 2);
+                t_aan[L] = len - P->word_len + 1 - (len - aa1) * P->word_len;
+            } else {
+                t_aas[L] = (int)(P->aas_cutoff * (double)len);
+                t_aan[L] = (int)(P->aan_cutoff * (double)len);
             }
+        }
+        std::vector<uint8_t> bad(nth, 0);
+        parallel_for(n, nth, [&](unsigned t, size_t b, size_t e) {   // (the lengths that occur: run boundaries of the sorted list)
+            for (size_t k = b; k < e; ++k)
+                if ((k == b || h_len[k] != h_len[k - 1]) && t_aas[h_len[k]] < 1) bad[t] = 1;
         });
         for (uint8_t b : bad) PGX_REQUIRE(!b, "aas_cutoff too small: every sequence needs required_aas >= 1");
         S.sum_len_queries = h_off[n];
@@ -2162,13 +2177,14 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_lines, d_pool[2], d_idx,
         d_newbits, d_touched, d_first, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
         d_ulist, d_new_list, d_flags, d_gscratch, d_order, d_list, d_gather, d_pk, d_pkoff,
-        d_counters2, d_best2, d_flags2, d_pairsW2, d_gscratch2;   // second set of a window's own state (see `overlap`)
+        d_counters2, d_best2, d_flags2, d_pairsW2, d_gscratch2,   // second set of a window's own state (see `overlap`)
+        d_thr;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_lines,
                          &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_best_own, &d_rcvis,
                          &d_counters, &d_visits, &d_pairsW, &d_pairsK, &d_blk_list, &d_ulist, &d_new_list, &d_flags,
                          &d_gscratch, &d_order, &d_list, &d_gather, &d_pk, &d_pkoff,
-                         &d_counters2, &d_best2, &d_flags2, &d_pairsW2, &d_gscratch2};
+                         &d_counters2, &d_best2, &d_flags2, &d_pairsW2, &d_gscratch2, &d_thr};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -2259,9 +2275,13 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                                                    d_pkoff.as<uint32_t>(), nv, d_pk.as<uint32_t>());
     }
     LAUNCH_CHECK();
-    PGX_HIP(hipMemcpyAsync(d_aa1.p, h_aa1.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    PGX_HIP(hipMemcpyAsync(d_aas.p, h_aas.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    PGX_HIP(hipMemcpyAsync(d_aan.p, h_aan.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    {   // thresholds per sequence from the per-length tables
+        PGX_HIP(d_thr.alloc(3 * ((size_t)max_len + 1) * 4));
+        PGX_HIP(hipMemcpyAsync(d_thr.p, h_thr.data(), 3 * ((size_t)max_len + 1) * 4, hipMemcpyHostToDevice, st));
+        thresholds_kernel<<<(n + 255) / 256, 256, 0, st>>>(d_len.as<uint32_t>(), n, d_thr.as<int32_t>(), max_len + 1,
+                                                          d_aa1.as<int32_t>(), d_aas.as<int32_t>(), d_aan.as<int32_t>());
+        LAUNCH_CHECK();
+    }
     PGX_HIP(hipMemsetAsync(d_visits.p, 0, 8, st));
 
     phase("alloc + upload + encode (enq)");
