@@ -289,7 +289,8 @@ def main():
             cnt = sum(pmc[n_].get('launches', 1) for n_ in names if n_ in pmc)
             return sum(vals) / cnt if cnt else None
         # kernel families of the clustering by accumulated device time (one profiled step)
-        fam = {'filter_kernel': ('filter_kernel<all>', 'filter_kernel<new>'), 'align_kernel': ('align_kernel',),
+        # (the block pass is the <true> instantiation of the filter too: rocprofv3 lists it with the passes over new entries)
+        fam = {'filter_kernel': ('filter_kernel<all>', 'filter_kernel<new>', 'filter_kernel<block>'), 'align_kernel': ('align_kernel',),
                'diag_kernel': ('diag_kernel',)}
         fam_ms = {f: sum(kern.get(k_, (0, 0))[0] for k_ in ks) for f, ks in fam.items()}
         fam_n = {f: sum(kern.get(k_, (0, 0))[1] for k_ in ks) for f, ks in fam.items()}
