@@ -1,6 +1,6 @@
 """Determinism of the overlapped window loop: the same set clustered several times with the windows overlapping on two
 streams and once without (PGX_NO_OVERLAP=1) must give identical clusters, members, identities and counters.
-Usage: python tools/overlap_check.py [workload] [repeats]"""
+Usage: python tools/overlap_check.py [workload] [repeats] [window]"""
 import os
 import sys
 
@@ -14,6 +14,8 @@ def main():
     repeats = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     res, off, _ = synth.protein_set(workload).nr_arrays()
     p = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
+    if len(sys.argv) > 3:
+        p.batch_size = int(sys.argv[3])     # window size (many small windows stress the hand-over between the streams)
     ctx = _native.Context(0)
     os.environ['PGX_NO_OVERLAP'] = '1'
     ref = ctx.cluster_greedy(res, off, p)
