@@ -1935,7 +1935,7 @@ extern "C" uint32_t pgx_cluster_window_cap(const pgx_cluster_params *P) {
     if (!P) return 0;
     const bool both = P->alphabet == 1 && P->both_strands != 0;
     // nucleotide rules at the reference's -n 5 -c 0.8 pass any pair that shares one word: small windows
-    uint32_t w = P->alphabet == 1 ? (both ? 2048u : 4096u) : 49152u;   // (proteins: 32768 -> 49152 = 42 -> 35 windows on cfg-3s, -4 ms; 65536: the same)
+    uint32_t w = P->alphabet == 1 ? (both ? 512u : 1024u) : 49152u;     // (nucleotides, 400-genome set: 512 -> 147 ms, 1024 -> 168, 2048 -> 231, 256 -> 173)   // (proteins: 32768 -> 49152 = 42 -> 35 windows on cfg-3s, -4 ms; 65536: the same)
     if (P->batch_size > 0) w = (uint32_t)P->batch_size;
     if (const char *e = std::getenv("PGX_WINDOW")) { const long v = std::atol(e); if (v > 0) w = (uint32_t)v; }
     w = std::max(w, 64u);
