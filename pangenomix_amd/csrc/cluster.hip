@@ -1935,7 +1935,7 @@ extern "C" uint32_t pgx_cluster_window_cap(const pgx_cluster_params *P) {
     if (!P) return 0;
     const bool both = P->alphabet == 1 && P->both_strands != 0;
     // nucleotide rules at the reference's -n 5 -c 0.8 pass any pair that shares one word: small windows
-    uint32_t w = P->alphabet == 1 ? (both ? 512u : 1024u) : 49152u;     // (nucleotides, 400-genome set: 512 -> 147 ms, 1024 -> 168, 2048 -> 231, 256 -> 173)   // (proteins: 32768 -> 49152 = 42 -> 35 windows on cfg-3s, -4 ms; 65536: the same)
+    uint32_t w = P->alphabet == 1 ? (both ? 512u : 1024u) : 65536u;     // (nucleotides, 400-genome set: 512 -> 147 ms, 1024 -> 168, 2048 -> 231, 256 -> 173; proteins: the chunk volume bounds the windows first)
     if (P->batch_size > 0) w = (uint32_t)P->batch_size;
     if (const char *e = std::getenv("PGX_WINDOW")) { const long v = std::atol(e); if (v > 0) w = (uint32_t)v; }
     w = std::max(w, 64u);
@@ -2141,7 +2141,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     const double thr_frac = P->identity > 0.95 ? std::max(0.0, 1.0 - (1.0 - P->identity) * P->word_len) : P->aan_cutoff;
     // (a code space too small for that -- nucleotide 5-mers, tiny thresholds -- gets one chunk per window: the
     // discovery test then certifies little and the exact block resolution does the work)
-    const uint64_t chunk_words = (uint64_t)(0.4 * thr_frac * (double)n_codes);
+    // (0.8 of the threshold fraction: unrelated members alone then share 17 % of their words with a chunk by chance,
+    // against a threshold of 23 %. Measured, cfg-3s / cfg-4 / 300,000 unrelated random proteins: 0.4 -> 101 ms / 1.57 s /
+    // 49 ms, 0.8 -> 94 ms / 1.3 s / 64 ms, 1.0 -> 93 ms / 1.26 s / 82 ms -- families fill far less of the code space than
+    // their word count, so larger chunks mean fewer, larger windows; without families the test starts to fail.)
+    static const double chunk_frac = std::getenv("PGX_CHUNK_FRAC") ? std::atof(std::getenv("PGX_CHUNK_FRAC")) : 0.8;
+    const uint64_t chunk_words = (uint64_t)(chunk_frac * thr_frac * (double)n_codes);
     const bool chunking = chunk_words >= 16384;
     auto form_window = [&](uint32_t b0, Chunks &C) -> uint32_t {
         C.n = 1; C.begin[0] = 0;

@@ -333,7 +333,7 @@ def test_cfg3s_full_size_parity(gpu_ctx):
     res, off, _ = synth.protein_set('cfg-3s').nr_arrays()
     p = params()
     got = gpu_ctx.cluster_greedy(res, off, p)
-    assert got[5]['sweeps'] >= 30
+    assert got[5]['sweeps'] >= 15
     assert_same(got, oracle.cluster_greedy(res, off, p))
 
 
