@@ -17,19 +17,23 @@
 // one wave per query walks the lines of the query's words, so a query touches exactly the posting
 // entries the sequential rule visits.
 //
-// One WINDOW handles up to 32768 consecutive queries (nucleotides, both strands: each query has a
-// second slot for its reverse complement):
+// One WINDOW handles up to 65536 consecutive queries (nucleotides, both strands: 512, each query with a
+// second slot for its reverse complement), bounded also by the word volume of its discovery chunks:
 //   phase A   filter over the whole index (representatives of earlier windows) -> candidate pairs
 //             -> diag (k-mer diagonal histogram, best band) -> align (banded DP on the anti-diagonal
 //             wavefront, four pairs per wave) -> best[q] = min key of the accepted pairs
-//   discovery still-open members that cannot have an earlier open candidate (linear-time word test)
-//             are certain new representatives: appended to the index at once; the filter then visits
-//             only the entries this round added, for all later members; twice, all on the device
-//   blocks    members still open are resolved <= 512 at a time, exactly: all in-block pairs are
-//             found and evaluated, the host walks the block in order, the block's new
-//             representatives are appended and compared with the later members
+//   discovery still-open members that cannot have an earlier open candidate (linear-time word test over
+//             per-chunk first-open tags) are certain new representatives: appended to the index at once
+//             (one pass), and the filter then visits, for all window members, only the entries this round
+//             added; twice, all on the device
+//   blocks    members still open are resolved <= 4096 at a time, exactly: they are appended to the index
+//             tentatively, the filter finds the in-block pairs, the host walks the block in order, the
+//             entries of the members that joined a representative are struck out again and every
+//             window member is compared with what is left
 //   close     winners, new representatives and pair records go to the host in one publish launch;
-//             the host's bookkeeping of a window runs behind the next window's first kernels.
+//             the host's bookkeeping of a window (and its outputs) runs behind the next window's kernels.
+// Consecutive windows overlap on two streams: the tail of a window (from its last strike-out on) only reads
+// the index, and so does phase A of the next; each has its own counters, best keys, flags and pair records.
 // Record-sharded mode (one process per GPU, pgx.h): window member i belongs to process i % W, which
 // filters and aligns it against its replica of the index; the members' best keys are all-gathered
 // (RCCL, enqueued on the stream) after every evaluation; discovery, index appends and the block
