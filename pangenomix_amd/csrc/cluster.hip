@@ -2150,7 +2150,10 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     // 49 ms, 0.8 -> 94 ms / 1.3 s / 64 ms, 1.0 -> 93 ms / 1.26 s / 82 ms -- families fill far less of the code space than
     // their word count, so larger chunks mean fewer, larger windows; without families the test starts to fail.)
     static const double chunk_frac = std::getenv("PGX_CHUNK_FRAC") ? std::atof(std::getenv("PGX_CHUNK_FRAC")) : 0.8;
-    const uint64_t chunk_words = (uint64_t)(chunk_frac * thr_frac * (double)n_codes);
+    // The fraction ADAPTS: a window that needed three or more blocks (the discovery test certified too little: members
+    // without families) halves it for the windows after, a window with at most one block raises it again.
+    double cur_frac = chunk_frac;
+    uint64_t chunk_words = (uint64_t)(cur_frac * thr_frac * (double)n_codes);
     const bool chunking = chunk_words >= 16384;
     auto form_window = [&](uint32_t b0, Chunks &C) -> uint32_t {
         C.n = 1; C.begin[0] = 0;
@@ -2216,6 +2219,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_idx.alloc(16));
     PGX_HIP(d_newbits.alloc(((size_t)n_codes / 32 + 2) * 4 + 16));
     PGX_HIP(d_touched.alloc((max_window_words + 16) * sizeof(Deferred)));   // entries set aside by an append round
+    if (chunking && n > window_cap / 2) max_chunks = kMaxChunks;   // (smaller chunks later may need all of them)
     uint32_t tag_stride = 1;   // first-open tags: one record of tag_stride >= max_chunks words per code
     while (tag_stride < max_chunks) tag_stride *= 2;
     PGX_HIP(d_first.alloc((size_t)tag_stride * n_codes * 4 + 16));
@@ -2782,6 +2786,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 if (rc) return rc;
             }
             if (n_open == n_blk) break;  // that was the last block
+        }
+        if (chunking) {   // the discovery chunks of the windows to come (see chunk_frac)
+            const uint64_t blk = n_blocks - blocks_before;
+            if (blk >= 3) cur_frac = std::max(0.1, cur_frac * 0.5);
+            else if (blk <= 1) cur_frac = std::min(chunk_frac, cur_frac * 1.5);
+            chunk_words = std::max<uint64_t>(16384, (uint64_t)(cur_frac * thr_frac * (double)n_codes));
         }
         // ---- close the window ---------------------------------------------------------------
         {   // counters, winners, and exactly the pair records that exist, in one launch
