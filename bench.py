@@ -64,6 +64,8 @@ def main():
                     help='CPU baseline: the oracle on the non-redundant set of the first K genomes (bounded sample)')
     ap.add_argument('--skip-cpu', action='store_true')
     ap.add_argument('--skip-e2e', action='store_true', help='skip the end-to-end build_cds_pangenome() measurement')
+    ap.add_argument('--skip-cfg4', action='store_true',
+                    help='N = 1 only: skip the one-GPU run of the 4000-genome shape (the reference point of the N > 1 series)')
     ap.add_argument('--e2e-genomes', type=int, default=0, help='genomes of the end-to-end run (0 = the whole workload)')
     ap.add_argument('--shard', choices=['records', 'replicas'], default='records',
                     help='N > 1: ONE clustering job sharded by record over the ranks (default, strong scaling) or N '
@@ -271,6 +273,33 @@ def main():
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
 
+        if world == 1 and not use_dist and workload == 'cfg-3s' and not args.skip_cfg4 and args.only == 'all':
+            # The N > 1 series splits ONE job of the 4000-genome shape (cfg-4) over the ranks: its one-GPU point,
+            # measured here so that the series has its reference in the same record (inputs resident, as above).
+            t = time.perf_counter()
+            p4 = synth.protein_set('cfg-4')
+            r4, o4, raw4 = p4.nr_arrays(progress=1000)
+            log('inputs: cfg-4 -> %d non-redundant of %d raw records, %.1f s' % (o4.size - 1, raw4, time.perf_counter() - t))
+            d_r4 = torch.from_numpy(r4.copy()).to(dev)
+            d_o4 = torch.from_numpy(o4.view(np.int64)).to(dev)
+            ctx.profile(False)
+            best4, out4 = None, None
+            for _ in range(3):                               # the first run sizes the workspace
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                out4 = ctx.cluster_greedy_dev(d_r4.data_ptr(), d_o4.data_ptr(), o4.size - 1, r4.size, base_params, stream)
+                torch.cuda.synchronize()
+                e = time.perf_counter() - t
+                best4 = e if best4 is None else min(best4, e)
+            l4 = np.diff(o4.astype(np.int64))
+            assert ((l4 <= 10) == (out4[0] < 0)).all() and (out4[2][out4[1] > 0] >= np.float32(0.8)).all(), 'cfg-4 properties'
+            extra['cfg4_one_gpu'] = {'value': (o4.size - 1) / best4, 'unit': 'proteins/s', 'ms': best4 * 1e3,
+                                     'proteins': int(o4.size - 1), 'clusters': int(out4[4]), 'windows': int(out4[5]['sweeps']),
+                                     'what': 'the 4000-genome synthetic shape (configs[3]) clustered on ONE GPU, inputs in HBM, '
+                                             'best of 3: the N = 1 point of the record-sharded series bench.py --gpus N runs'}
+            del d_r4, d_o4, r4, o4
+            torch.cuda.empty_cache()
+
         kern = {k: (v[0], v[1]) for k, v in prof_all.items()}   # one profiled step: (ms, launches)
         words = (G + 63) // 64
         pc_bytes = my_iter * (S * words * 8 + 2 * S * 4) + my_iter * S * 4
@@ -376,6 +405,7 @@ def main():
                         'achieved_GBs': extra['cl_gbs'], 'frac_hbm': extra['cl_gbs'] / HBM_PEAK_GBS,
                         'dp_cells_per_s': st['dp_cells'] / (t_cluster / steps), 'stats': st},
             'end_to_end': extra.get('end_to_end'),
+            'cfg4_one_gpu': extra.get('cfg4_one_gpu'),
             'roofline': extra['roofline'],
             'cpu_baseline': extra['cpu'],
             'kernels_ms_per_step': {k_: {'ms': round(v[0], 4), 'launches': v[1]} for k_, v in sorted(extra['kern'].items())},
