@@ -10,11 +10,17 @@ region starts:
 
 N = 1: the 400-genome workload the metric is quoted on (BASELINE.json configs[2]; the Bacteroides
 files are not available offline, so the deterministic synthetic stand-in `cfg-3s` of SURVEY.md 8d:
-400 genomes x 4,500 CDS). N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL):
-ONE clustering job of the 4000-genome shape `cfg-4` (configs[3]) split over the ranks by record --
-window member i is filtered and aligned by rank i % N, best keys all-gathered over xGMI -- and the
-pan/core iterations split by iteration: "strong" scaling. `--shard replicas` (explicit) runs N
-independent copies instead.
+400 genomes x 4,500 CDS). N > 1, one rank per GPU over RCCL: ONE clustering job of the 4000-genome
+shape `cfg-4` (configs[3]) split over the ranks by record -- window member i is filtered and aligned
+by rank i % N, best keys all-gathered over xGMI -- and the pan/core iterations split by iteration:
+"strong" scaling; rank 0 also runs the same job unsharded once, so the line carries `one_gpu_ms` and
+`speedup_vs_one_gpu` measured in the same run. `--workload cfg-4` at N = 1 gives the series' first
+point with the same workload. `--shard replicas` (explicit) runs N independent copies instead.
+
+Launch: `python bench.py --gpus N` starts the N ranks itself (a child `python -m
+torch.distributed.run --nproc-per-node N ... bench.py ...`, before this process touches a GPU, and
+relays its JSON line and exit code); under a launcher (RANK / WORLD_SIZE in the environment) it is
+one of the ranks and WORLD_SIZE must equal --gpus.
 
 `value` is proteins/s of (a): sequences handed to the clustering call / its time. Beside the timed
 steps, rank 0 measures once each (reported, never part of `value`): the host-pointer entry point
@@ -52,6 +58,74 @@ def cluster_terms(st, bits=5):
             'rep_words': 4 * st['rep_words'], 'outputs': 12 * st['n_clustered']}
 
 
+def cdhit_reference(sres, soff, got_cluster, got_member, workdir):
+    """if a real cd-hit is on PATH, run it on the CPU sample exactly as the reference does
+    (pangenome.py:444-447: `cd-hit -i nr.faa -o nr.faa.cdhit -d 0 -n 5 -c 0.8`; one thread, default -M 800) and once
+    more with `-T 0 -M 0` (all cores, unchunked), and compare the membership with the GPU result on the same
+    sequences. Returns None when the program is absent (the usual case: it cannot be installed offline)."""
+    import subprocess
+    exe = shutil.which('cd-hit')
+    if exe is None:
+        return None
+    n = soff.size - 1
+    faa = os.path.join(workdir, 'sample_nr.faa')
+    text = sres.tobytes().decode('ascii')
+    with open(faa, 'w') as f:
+        for i in range(n):
+            f.write('>s%d\n%s\n' % (i, text[int(soff[i]):int(soff[i + 1])]))
+    rep_got = np.full(n, -1, dtype=np.int64)                 # per sequence: the representative of its cluster
+    reps = np.flatnonzero(got_member == 0)
+    by_cluster = np.full(int(got_cluster.max()) + 2, -1, dtype=np.int64)
+    by_cluster[got_cluster[reps]] = reps
+    rep_got[got_cluster >= 0] = by_cluster[got_cluster[got_cluster >= 0]]
+    out = {'path': exe}
+    for tag, more in (('as_reference', []), ('all_cores_unchunked', ['-T', '0', '-M', '0'])):
+        o = os.path.join(workdir, 'sample_nr.faa.cdhit.' + tag)
+        t = time.perf_counter()
+        rc = subprocess.call([exe, '-i', faa, '-o', o, '-d', '0', '-n', '5', '-c', '0.8'] + more,
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.perf_counter() - t
+        if rc != 0 or not os.path.exists(o + '.clstr'):
+            out[tag] = {'error': 'cd-hit exited with %d' % rc}
+            continue
+        rep_ref = np.full(n, -1, dtype=np.int64)
+        members, rep = [], -1
+        with open(o + '.clstr') as f:
+            for line in f:
+                if line.startswith('>'):
+                    for m_ in members:
+                        rep_ref[m_] = rep
+                    members, rep = [], -1
+                    continue
+                tok = line.split()
+                idx = int(tok[2][2:].rstrip('.'))              # '>s<i>...'
+                members.append(idx)
+                if tok[-1] == '*':
+                    rep = idx
+        for m_ in members:
+            rep_ref[m_] = rep
+        differ = int((rep_ref != rep_got).sum())
+        out[tag] = {'value': n / dt, 'unit': 'proteins/s', 'seconds': dt, 'clusters': int((rep_ref == np.arange(n)).sum()),
+                    'membership_equal': differ == 0, 'sequences_in_a_different_cluster': differ}
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never exec: this
+    process must not have touched a GPU, and it has not) and relay its output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('bench.py: starting %d ranks: %s' % (n, ' '.join(cmd)))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -73,6 +147,14 @@ def main():
     ap.add_argument('--only', choices=['all', 'cluster', 'pancore'], default='all',
                     help='restrict the step (used for rocprofv3 counter passes); the JSON line needs all')
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be at least 1')
+    if 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args.gpus))
+    elif int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        raise SystemExit('bench.py: launched with WORLD_SIZE=%s but --gpus %d: they must agree (the line reports '
+                         'n_gpus = the ranks that really ran)' % (os.environ.get('WORLD_SIZE'), args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -82,6 +164,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.device_count() < max(world, local_rank + 1):   # (counting devices does not initialise one)
+        raise SystemExit('bench.py: %d rank(s) asked for, %d GPU(s) visible: one GPU per rank is needed (no CPU '
+                         'fallback, no two ranks on one card)' % (world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (there is no CPU fallback)')
     torch.cuda.set_device(local_rank)
@@ -273,6 +358,25 @@ def main():
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
 
+        if sharded and args.only == 'all':
+            # The same job, unsharded, on rank 0's GPU in the same run (the other ranks wait at the barrier):
+            # the reference point of this line's value, and a parity check of the folded multi-rank result.
+            ctx.profile(False)
+            best1, out1 = None, None
+            for _ in range(2):                               # (the first run sizes the second window set)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                out1 = ctx.cluster_greedy_dev(d_res.data_ptr(), d_off.data_ptr(), n_nr, res.size, base_params, stream)
+                torch.cuda.synchronize()
+                e = time.perf_counter() - t
+                best1 = e if best1 is None else min(best1, e)
+            assert np.array_equal(out1[0], cl) and np.array_equal(out1[1], mem) and np.array_equal(out1[2], iden), \
+                'record-sharded result differs from the one-GPU result'
+            s1, sN = dict(out1[5]), dict(st)
+            for d_ in (s1, sN):
+                d_.pop('sweeps'), d_.pop('gpu')
+            assert s1 == sN, 'record-sharded counters differ from the one-GPU counters'
+            extra['one_gpu_ms'] = best1 * 1e3
         if world == 1 and not use_dist and workload == 'cfg-3s' and not args.skip_cfg4 and args.only == 'all':
             # The N > 1 series splits ONE job of the 4000-genome shape (cfg-4) over the ranks: its one-GPU point,
             # measured here so that the series has its reference in the same record (inputs resident, as above).
@@ -367,9 +471,15 @@ def main():
             t1 = time.perf_counter()
             oracle.pan_core(row, col, None, G, S, perms[:k])
             pdt = time.perf_counter() - t1
+            tmpc = tempfile.mkdtemp(prefix='pgx_cdhit_')
+            try:
+                ref = cdhit_reference(sres, soff, gcl[0], gcl[1], tmpc)
+            finally:
+                shutil.rmtree(tmpc, ignore_errors=True)
             cpu = {'value': (soff.size - 1) / cdt, 'unit': 'proteins/s', 'cores': 1, 'kind': 'port',
                    'host_cores_available': os.cpu_count(),
-                   'sample': 'own restatement (oracle/cluster_ref.c, sequential; cd-hit itself is not installed) on the '
+                   'cd_hit': ref if ref is not None else 'probed (shutil.which("cd-hit")): absent on this host',
+                   'sample': 'own restatement (oracle/cluster_ref.c, sequential) on the '
                              'non-redundant set of the first %d of %d genomes: %d sequences, %d clusters, %.1f s on one core. '
                              'The rule is sequential, so there is no all-cores figure; the per-sequence cost grows with '
                              'the table: the full 400-genome set runs at about 16 k proteins/s (DESIGN.md).'
@@ -377,6 +487,8 @@ def main():
                    'pan_core': {'value': k / pdt, 'unit': 'iters/s', 'cores': 1,
                                 'sample': '%d of %d iterations, oracle/pancore_ref.c (dense incidence loop of '
                                           'pangenome_analysis.py:81-90)' % (k, n_iter)}}
+            if ref is not None and 'value' in ref.get('as_reference', {}):   # the real program ran: it is the baseline
+                cpu.update(kind='reference', value=ref['as_reference']['value'], port_value=(soff.size - 1) / cdt)
         extra['cpu'] = cpu
     barrier()
     if rank == 0:
@@ -404,6 +516,8 @@ def main():
                         'algorithmic_bytes': extra['cl_bytes'], 'algorithmic_terms': extra['terms'],
                         'achieved_GBs': extra['cl_gbs'], 'frac_hbm': extra['cl_gbs'] / HBM_PEAK_GBS,
                         'dp_cells_per_s': st['dp_cells'] / (t_cluster / steps), 'stats': st},
+            'one_gpu_ms': extra.get('one_gpu_ms'),
+            'speedup_vs_one_gpu': (extra['one_gpu_ms'] / (t_cluster / steps * 1e3)) if extra.get('one_gpu_ms') else None,
             'end_to_end': extra.get('end_to_end'),
             'cfg4_one_gpu': extra.get('cfg4_one_gpu'),
             'roofline': extra['roofline'],

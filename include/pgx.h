@@ -64,7 +64,12 @@ typedef struct pgx_device_info_t {
 
 int pgx_version(void);
 const char *pgx_last_error(void);
+/* One context = ONE device. SURVEY 8b sketched `pgx_ctx_create(const int *device_ids, int n_devices, ...)`; the
+ * build deliberately deviates: the multi-GPU mode is one PROCESS per GPU (torch.distributed / RCCL, see
+ * pgx_cluster_params.shard_*), each process with its own single-device context, so a context never spans
+ * devices. pgx_ctx_create_on() takes the surveyed argument shape and accepts exactly one device id. */
 int pgx_ctx_create(int device_id, pgx_ctx **out);
+int pgx_ctx_create_on(const int *device_ids, int n_devices, pgx_ctx **out);
 void pgx_ctx_destroy(pgx_ctx *ctx);
 int pgx_device_info(pgx_ctx *ctx, pgx_device_info_t *out);
 
@@ -217,8 +222,10 @@ int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const uint64_t *of
                        float *out_identity, uint8_t *out_strand, uint32_t *out_n_clusters,
                        pgx_cluster_stats *stats);
 /* Same, with the sequences already resident in HBM: d_residues / d_offsets are DEVICE
- * pointers (total_bytes = offsets[n]); the out_* arrays and stats are HOST memory. All work
- * is enqueued on `stream`; the call returns after the last sweep has been resolved. */
+ * pointers (total_bytes = offsets[n]); the out_* arrays and stats are HOST memory. The inputs are
+ * read on `stream` (work already enqueued there is waited for); consecutive windows then alternate
+ * between `stream` and a second, lower-priority stream of the context, ordered by events. The call
+ * returns after the last window has been resolved and both streams have drained. */
 /* queries per window the library will use for these parameters (env PGX_WINDOW overrides) */
 uint32_t pgx_cluster_window_cap(const pgx_cluster_params *params);
 int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_offsets, uint32_t n,

@@ -84,6 +84,7 @@ SIGNATURES = {
     'pgx_version': (C.c_int, []),
     'pgx_last_error': (C.c_char_p, []),
     'pgx_ctx_create': (C.c_int, [C.c_int, C.POINTER(_P)]),
+    'pgx_ctx_create_on': (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
     'pgx_ctx_destroy': (None, [_P]),
     'pgx_device_info': (C.c_int, [_P, C.POINTER(DeviceInfo)]),
     'pgx_profile_enable': (C.c_int, [_P, C.c_int]),
@@ -161,7 +162,12 @@ def lib():
 
 def check(rc):
     if rc != 0:
-        raise PgxError('libpgx error %d: %s' % (rc, lib().pgx_last_error().decode('utf-8', 'replace')))
+        err = PgxError('libpgx error %d: %s' % (rc, lib().pgx_last_error().decode('utf-8', 'replace')))
+        err.status = rc
+        raise err
+
+
+ERR_NOMEM = -4   # PGX_ERR_NOMEM
 
 
 def _ptr(a):

@@ -2181,6 +2181,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             max_chunks = std::max(max_chunks, C.n);
         }
     }
+    // The chunk volume adapts (cur_frac below), so later windows are not the ones of this scan: bound a window's words
+    // independently of the partition -- no more than the window_cap longest sequences, no more than kMaxChunks
+    // chunks of the largest volume (a chunk closes before it would exceed that, or holds one sequence).
+    if (chunking)
+        max_window_words = std::max<uint64_t>(max_window_words,
+            std::min<uint64_t>(h_off[std::min(n, window_cap)], (uint64_t)kMaxChunks * std::max<uint64_t>(chunk_words, max_len)));
     PGX_REQUIRE(max_window_words < 0xFFFFFFF0ull, "window too large");
     const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsSmall;
     const uint32_t diag_grid = 8192, align_grid = 1024;  // diag: one wave per pair, ~11 workgroups fit a CU

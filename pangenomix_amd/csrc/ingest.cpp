@@ -29,6 +29,9 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <memory>
+#include <new>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -198,15 +201,37 @@ void parse_file(FileData &F, uint32_t file_id) {
         if (F.recs[r].seq_len) sha256(F.seq.data() + F.recs[r].seq_off, F.recs[r].seq_len, &F.digest[r * 32]);
 }
 
+// An exception in a worker (std::bad_alloc from the vectors and strings the items grow) must not reach
+// std::terminate: the workers catch, the first failure stops the hand-out of items, and the CALLING thread throws
+// once everybody has joined -- from there the guards of the C ABI (`guarded`) turn it into a status code.
 template <typename F>
 void parallel_for(size_t n, int threads, F f) {
     std::atomic<size_t> next{0};
-    auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) f(i); };
+    std::atomic<int> failed{0};                 // 1 = out of memory, 2 = anything else
+    auto work = [&]() {
+        try {
+            for (size_t i; !failed.load(std::memory_order_relaxed) && (i = next.fetch_add(1)) < n;) f(i);
+        } catch (const std::bad_alloc &) { failed = 1; }
+        catch (...) { int none = 0; failed.compare_exchange_strong(none, 2); }
+    };
     std::vector<std::thread> pool;
     const int t = std::max(1, std::min<int>(threads, (int)n));
-    for (int k = 1; k < t; ++k) pool.emplace_back(work);
+    try {
+        for (int k = 1; k < t; ++k) pool.emplace_back(work);
+    } catch (...) { failed = 2; }               // (no more threads to be had: what was started finishes the items)
     work();
     for (auto &th : pool) th.join();
+    if (failed == 1) throw std::bad_alloc();
+    if (failed) throw std::runtime_error("a worker thread failed");
+}
+
+// Every entry point of the C ABI that allocates runs inside this guard: no exception crosses the boundary (pgx.h).
+template <typename F>
+int guarded(const char *fn, F body) {
+    try { return body(); }
+    catch (const std::bad_alloc &) { pgx_set_error("%s: out of host memory", fn); return PGX_ERR_NOMEM; }
+    catch (const std::exception &e) { pgx_set_error("%s: %s", fn, e.what()); return PGX_ERR_INTERNAL; }
+    catch (...) { pgx_set_error("%s: unexpected exception", fn); return PGX_ERR_INTERNAL; }
 }
 
 struct Out {   // buffered file writer
@@ -285,11 +310,11 @@ struct pgx_fasta_set {
 
 extern "C" {
 
-int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pgx_fasta_set **out) {
+static int pgx_fasta_open_impl(const char *const *paths, uint32_t n_paths, int n_threads, pgx_fasta_set **out) {
     if (!out || (n_paths && !paths)) { pgx_set_error("pgx_fasta_open: NULL argument"); return PGX_ERR_INVALID; }
     *out = nullptr;
-    auto *S = new (std::nothrow) pgx_fasta_set();
-    if (!S) { pgx_set_error("pgx_fasta_open: out of memory"); return PGX_ERR_NOMEM; }
+    std::unique_ptr<pgx_fasta_set> holder(new pgx_fasta_set());   // (released to the caller at the end; freed on every other way out)
+    pgx_fasta_set *S = holder.get();
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     S->threads = n_threads;
     S->files.resize(n_paths);
@@ -320,7 +345,6 @@ int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pg
     });
     if (failed >= 0) {
         pgx_set_error("pgx_fasta_open: cannot read %s", S->paths[(size_t)failed].c_str());
-        delete S;
         return PGX_ERR_INVALID;
     }
     lap("read + parse + sha256");
@@ -330,7 +354,7 @@ int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pg
         S->first_rec[i + 1] = S->first_rec[i] + S->files[i].recs.size();
     }
     S->n_records = S->first_rec[n_paths];
-    if (!S->simple) { *out = S; return PGX_OK; }   // the caller takes its own path; nothing else is built
+    if (!S->simple) { *out = holder.release(); return PGX_OK; }   // the caller takes its own path; nothing else is built
     const uint64_t R = S->n_records;
     S->group_of.assign(R, -1);
     S->file_of.resize(R);
@@ -484,7 +508,7 @@ int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pg
         }
     }
     lap("header check");
-    *out = S;
+    *out = holder.release();
     return PGX_OK;
 }
 
@@ -526,7 +550,7 @@ static void put_header(Out &o, const pgx_fasta_set *S, uint64_t r) {
 // consolidate_seqs()'s three files (pangenome.py:374-403): the non-redundant FASTA (first-seen records, the
 // stripped sequence lines as they were wrapped), the groups with more than one header (encounter order,
 // tab-separated), the headers without sequence.
-int pgx_fasta_write_consolidated(const pgx_fasta_set *S, const char *nr_path, const char *shared_path,
+static int pgx_fasta_write_consolidated_impl(const pgx_fasta_set *S, const char *nr_path, const char *shared_path,
                                  const char *missing_path) {
     if (!S || !S->simple || !shared_path) { pgx_set_error("pgx_fasta_write_consolidated: invalid argument"); return PGX_ERR_INVALID; }
     if (nr_path) {
@@ -570,7 +594,7 @@ int pgx_fasta_write_consolidated(const pgx_fasta_set *S, const char *nr_path, co
 //   names_path   <prefix><cluster><variant><member> \t header \t synonyms...   in .clstr order
 //   nr_out_path  the non-redundant FASTA again with the allele names as headers; unclustered records dropped
 // NULL paths are skipped.
-int pgx_fasta_write_clustered(const pgx_fasta_set *S, const int32_t *cluster, const int32_t *member,
+static int pgx_fasta_write_clustered_impl(const pgx_fasta_set *S, const int32_t *cluster, const int32_t *member,
                               const float *identity, const uint8_t *strand, int nucleotide, const char *prefix,
                               const char *variant, const char *clstr_path, const char *names_path,
                               const char *nr_out_path) {
@@ -720,7 +744,7 @@ int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cl
 
 /* the same names as numpy 'U<width>' records (UCS-4 code points, zero padded), written by several threads;
  * prefix and variant must be ASCII */
-int pgx_format_labels_ucs4(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
+static int pgx_format_labels_ucs4_impl(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
                            uint64_t n, uint32_t width, uint32_t *out) {
     if (!prefix || !cluster || (variant && !member) || (n && !out)) { pgx_set_error("pgx_format_labels_ucs4: NULL argument"); return PGX_ERR_INVALID; }
     const size_t pl = strlen(prefix), vl = variant ? strlen(variant) : 0;
@@ -753,6 +777,28 @@ int pgx_format_labels_ucs4(const char *prefix, const char *variant, const int32_
     });
     if (bad) { pgx_set_error("pgx_format_labels_ucs4: %s", bad == 2 ? "width too small" : "labels longer than 64 characters"); return PGX_ERR_INVALID; }
     return PGX_OK;
+}
+
+// the allocating entry points behind their exception guards
+int pgx_fasta_open(const char *const *paths, uint32_t n_paths, int n_threads, pgx_fasta_set **out) {
+    return guarded("pgx_fasta_open", [&] { return pgx_fasta_open_impl(paths, n_paths, n_threads, out); });
+}
+int pgx_fasta_write_consolidated(const pgx_fasta_set *S, const char *nr_path, const char *shared_path,
+                                 const char *missing_path) {
+    return guarded("pgx_fasta_write_consolidated", [&] { return pgx_fasta_write_consolidated_impl(S, nr_path, shared_path, missing_path); });
+}
+int pgx_fasta_write_clustered(const pgx_fasta_set *S, const int32_t *cluster, const int32_t *member,
+                              const float *identity, const uint8_t *strand, int nucleotide, const char *prefix,
+                              const char *variant, const char *clstr_path, const char *names_path,
+                              const char *nr_out_path) {
+    return guarded("pgx_fasta_write_clustered", [&] {
+        return pgx_fasta_write_clustered_impl(S, cluster, member, identity, strand, nucleotide, prefix, variant, clstr_path,
+                                              names_path, nr_out_path);
+    });
+}
+int pgx_format_labels_ucs4(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
+                           uint64_t n, uint32_t width, uint32_t *out) {
+    return guarded("pgx_format_labels_ucs4", [&] { return pgx_format_labels_ucs4_impl(prefix, variant, cluster, member, n, width, out); });
 }
 
 }  // extern "C"

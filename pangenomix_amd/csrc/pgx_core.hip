@@ -129,6 +129,18 @@ int pgx_ctx_create(int device_id, pgx_ctx **out) {
     return PGX_OK;
 }
 
+int pgx_ctx_create_on(const int *device_ids, int n_devices, pgx_ctx **out) {
+    PGX_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    PGX_REQUIRE(device_ids != nullptr && n_devices >= 1, "no device given");
+    if (n_devices != 1) {
+        pgx_set_error("pgx_ctx_create_on: %d devices asked for; a context owns ONE device -- the multi-GPU mode is one "
+                      "process per GPU (pgx_cluster_params.shard_index / shard_count), each with its own context", n_devices);
+        return PGX_ERR_INVALID;
+    }
+    return pgx_ctx_create(device_ids[0], out);
+}
+
 void pgx_ctx_destroy(pgx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device_id);

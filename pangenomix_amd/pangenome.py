@@ -437,7 +437,13 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
             now = time.perf_counter()
             print('[pgx] pipeline: %-28s %8.1f ms' % (what, (now - t_mark[0]) * 1e3), file=sys.stderr)
             t_mark[0] = now
-    fs = _native.FastaSet(genome_paths)
+    try:
+        fs = _native.FastaSet(genome_paths)
+    except _native.PgxError as exc:
+        if getattr(exc, 'status', 0) != _native.ERR_NOMEM:
+            raise
+        print('Note: taking the step-by-step path (%s)' % exc)   # the native ingest holds 2-3x the input in memory
+        return None
     lap('ingest (parse, sha256, dedupe)')
     try:
         if not fs.simple:

@@ -42,23 +42,40 @@ class LightSparseDataFrame(object):
         self.index = np.asarray(index)       # (label arrays of a million names are not copied again)
         self.columns = np.asarray(columns)
         self.shape = self.data.shape
-        self._index_map = self._column_map = None   # label -> position, built on first use (:199-200)
+        # label -> position (:199-200), built on first use FROM THE CONSTRUCTION-TIME LABELS: the reference fills
+        # both dicts in __init__ and never refreshes them, so re-assigning .index / .columns afterwards (as
+        # build_noncoding_pangenome does, pangenome.py:292-293) leaves labelslice() resolving the old names
+        # (SURVEY App. B.5). The label arrays are kept by reference, not copied.
+        self._index0, self._columns0 = index, columns
+        self._index_map = self._column_map = None
         if len(index) != self.shape[0]:
             print('ERROR: Index length does not match data')
         if len(columns) != self.shape[1]:
             print('ERROR: Column length does no match data')
 
+    @staticmethod
+    def _label_map(labels):
+        return {label: i for i, label in enumerate(labels.tolist() if hasattr(labels, 'tolist') else labels)}
+
     @property
     def index_map(self):
         if self._index_map is None:
-            self._index_map = {label: i for i, label in enumerate(self.index.tolist() if hasattr(self.index, 'tolist') else self.index)}
+            self._index_map = self._label_map(self._index0)
         return self._index_map
+
+    @index_map.setter
+    def index_map(self, value):
+        self._index_map = value
 
     @property
     def column_map(self):
-        if self._column_map is None:   # (as the reference, not refreshed when .columns is re-assigned: App. B.5)
-            self._column_map = {label: i for i, label in enumerate(self.columns.tolist() if hasattr(self.columns, 'tolist') else self.columns)}
+        if self._column_map is None:
+            self._column_map = self._label_map(self._columns0)
         return self._column_map
+
+    @column_map.setter
+    def column_map(self, value):
+        self._column_map = value
 
     # -- output contract ---------------------------------------------------
     def to_npz(self, npz_file, label_file=None):

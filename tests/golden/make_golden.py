@@ -201,6 +201,7 @@ def make_pancore():
     cases = {
         'basic': dict(G=300, S=12, density=0.3, seed=1, iters=7),
         'one_genome': dict(G=70, S=1, density=0.5, seed=2, iters=3),
+        'two_genomes': dict(G=90, S=2, density=0.6, seed=8, iters=4),            # the smallest table a Heaps fit accepts
         'all_ones': dict(G=64, S=9, density=1.1, seed=3, iters=4),
         'zero_row_odd_words': dict(G=131, S=17, density=0.2, seed=4, iters=5),   # G not a multiple of 64
         'wide': dict(G=5000, S=70, density=0.05, seed=5, iters=6),              # > 64 steps: parked-lane wrap

@@ -56,8 +56,8 @@ def main():
     n = 0
     for path in sorted(glob.glob(os.path.join(HERE, 'pancore', '*.npz'))):
         z = np.load(path)
-        if int(z['shape'][1]) < 3:
-            continue                                        # curve_fit needs more points than parameters
+        if int(z['shape'][1]) < 2:
+            continue                                        # curve_fit (leastsq) refuses fewer points than parameters
         df = pd.DataFrame(z['expected'], index=[str(x) for x in z['index']], columns=[str(x) for x in z['columns']])
         fit = ref_pa.fit_heaps_by_iteration(df)
         np.savez_compressed(os.path.join(out, 'heaps_' + os.path.basename(path)), alpha=fit['alpha'].values,

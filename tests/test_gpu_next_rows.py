@@ -82,3 +82,16 @@ def test_occurrence_counts_full_size(gpu_ctx, tmp_path):
     scipy.sparse.save_npz(path, scipy.sparse.coo_matrix((np.ones(row2.size, np.int64), (row2, col2)), shape=(G, 400)))
     df2 = core_genome.count_gene_occurence(path, ctx=gpu_ctx)
     assert np.array_equal(df2['count'].values, np.bincount(row2, minlength=G)[counts > 0])
+
+
+def test_heaps_fit_of_two_genomes_is_the_exact_two_point_fit(gpu_ctx):
+    """scipy's leastsq refuses only fewer points than parameters: the reference fits a 2-genome table exactly
+    (fixture heaps_two_genomes, produced by the reference); one genome raises TypeError there and here."""
+    z = np.load(os.path.join(HERE, 'golden', 'pancore', 'two_genomes.npz'))
+    df = pd.DataFrame(z['expected'], index=[str(x) for x in z['index']], columns=[str(x) for x in z['columns']])
+    fit = pa.fit_heaps_by_iteration(df, ctx=gpu_ctx)
+    pan = df.values[:, :2]
+    np.testing.assert_allclose(fit['kappa'].values, pan[:, 0], rtol=1e-9)
+    np.testing.assert_allclose(fit['alpha'].values, np.log2(pan[:, 1] / pan[:, 0]), rtol=1e-9)
+    with pytest.raises(TypeError):
+        pa.fit_heaps_by_iteration(df.iloc[:, [0, 2]], ctx=gpu_ctx)

@@ -137,3 +137,20 @@ def test_small_helpers():
     assert pg.reverse_complement('ACGTNacgtRYKM') == 'KMRYacgtNACGT'
     with pytest.raises(KeyError):
         pg.reverse_complement('ACGX')
+
+
+def test_label_maps_are_the_construction_time_maps():
+    """SURVEY App. B.5 (reference sparse_utils.py:199-200, pangenome.py:292-293): index_map / column_map are filled
+    when the frame is built and never refreshed, so after `.columns` is re-assigned labelslice() still resolves the
+    OLD names; the maps are plain attributes a caller may replace."""
+    import scipy.sparse
+    df = su.LightSparseDataFrame(['g0', 'g1'], ['a_noncoding', 'b_noncoding'],
+                                           scipy.sparse.coo_matrix(np.array([[1, 0], [1, 1]])))
+    df.columns = np.array(['a', 'b'])
+    assert df.column_map == {'a_noncoding': 0, 'b_noncoding': 1}
+    assert df.labelslice(columns=['b_noncoding']).values.tolist() == [[0], [1]]
+    with pytest.raises(KeyError):
+        df.labelslice(columns=['b'])
+    df.column_map = {'a': 0, 'b': 1}
+    assert df.labelslice(columns=['b']).values.tolist() == [[0], [1]]
+    assert df.index_map == {'g0': 0, 'g1': 1}
