@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PGX_VERSION 200 /* 0.2.0 */
+#define PGX_VERSION 300 /* 0.3.0 */
 #define PGX_EXCHANGE_KEYS 65536u /* keys per process and exchange = the largest window */
 
 typedef enum pgx_status {
@@ -185,6 +185,18 @@ typedef struct pgx_cluster_params {
     void *exchange_user;
     void *exchange_send;    /* device, PGX_EXCHANGE_KEYS uint64 (the caller's allocation, so that */
     void *exchange_recv;    /* device, shard_count * PGX_EXCHANGE_KEYS uint64   its collective library can address it) */
+    /* cd-hit's MEMORY-CHUNKED rule, optional emulation. cd-hit bounds its word table by what is left
+     * of `-M` (default 800 MB; the reference's call passes no -M, pangenome.py:444-447): when the table is full,
+     * every sequence not yet clustered is compared with the current table at once (and joins the first
+     * representative that accepts it), the table is emptied, and clustering goes on with what is left. A
+     * sequence therefore joins a representative of the EARLIEST chunk that accepts it, which can differ from the
+     * unchunked winner. Where cd-hit places the boundaries depends on its memory accounting, which cannot be
+     * reproduced offline, so they are an input: positions in the length-sorted list of the clustered sequences
+     * (those longer than min_length), strictly increasing, each in (0, n_clustered); position b means "the table
+     * is flushed before the b-th sequence of that list is processed". NULL / 0 = the unchunked rule (-M 0). */
+    const uint32_t *chunk_boundaries;
+    uint32_t n_chunk_boundaries;
+    uint32_t reserved0;
 } pgx_cluster_params;
 
 /* Instrumentation that defines the roofline denominator. All are

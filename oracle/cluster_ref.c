@@ -18,8 +18,10 @@
  * refer to cd-hit 4.8.1 cdhit-common.c++ by recollection only. Known open points:
  *   - cd-hit's statistical filter table naa_stat[5][61][4] is not recoverable offline;
  *     the two cut-offs it feeds are therefore INPUTS (params->aan_cutoff/aas_cutoff);
- *   - cd-hit's default `-M 800` flushes the word table when memory fills (A.6); this
- *     restatement implements the memory-independent, unchunked rule.
+ *   - cd-hit's default `-M 800` flushes the word table when memory fills (A.6). Where it does so
+ *     depends on its memory accounting, which cannot be restated offline: the flush positions are an
+ *     INPUT (params->chunk_boundaries, positions in the sorted list); without them this is the
+ *     memory-independent, unchunked rule (`-M 0`).
  * What it pins instead: the HIP path must reproduce this file bit-for-bit (cluster ids,
  * member numbers, float identities, counters), and tests/test_cluster_oracle.py holds
  * known-answer cases (identical sequences, threshold straddling, discard length, ordering).
@@ -516,13 +518,42 @@ int pgxo_cluster_greedy(const uint8_t *residues, const uint64_t *offsets, uint32
     uint32_t *member_count = (uint32_t *)calloc((size_t)S.n + 1, sizeof(uint32_t));
     if (!member_count) goto done;
 
-    /* main greedy pass ("DoClustering" / "ClusterOne"), unchunked (A.6) */
+    /* main greedy pass ("DoClustering" / "ClusterOne"). A.6, the memory-chunked rule: at a chunk boundary every
+     * sequence not yet clustered is checked against the current table ("CheckOne": it joins the first
+     * representative that accepts it and is out of the game), then the table is emptied. */
+    uint8_t *taken = (uint8_t *)calloc((size_t)S.n + 1, 1);
+    if (!taken) { free(member_count); goto done; }
+    uint32_t next_bd = 0;
+    for (uint32_t i = 0; i < P->n_chunk_boundaries; ++i) {
+        const uint32_t b = P->chunk_boundaries[i];
+        if (b == 0 || b >= S.n || (i && b <= P->chunk_boundaries[i - 1])) {
+            rc = PGX_ERR_INVALID; free(member_count); free(taken); goto done;
+        }
+    }
     for (uint32_t q = 0; q < S.n; ++q) {
         uint32_t nw = 0, hit_rep = 0; float hit_iden = 0.0f; int hit_strand = 0;
+        if (next_bd < P->n_chunk_boundaries && q == P->chunk_boundaries[next_bd]) {
+            ++next_bd;
+            for (uint32_t k = q; k < S.n; ++k) {
+                if (taken[k]) continue;
+                const int hit = check_one(&S, k, P, &nw, &hit_rep, &hit_iden, &hit_strand);
+                if (hit < 0) { free(member_count); free(taken); goto done; }
+                if (!hit) continue;
+                taken[k] = 1;
+                const uint32_t o = S.orig[k];
+                if (out_cluster) out_cluster[o] = (int32_t)hit_rep;
+                if (out_member) out_member[o] = (int32_t)member_count[hit_rep];
+                if (out_identity) out_identity[o] = hit_iden;
+                if (out_strand) out_strand[o] = (uint8_t)hit_strand;
+                member_count[hit_rep]++;
+            }
+            for (uint32_t c = 0; c < S.n_codes; ++c) S.table[c].size = 0;   /* "word_table.Clear()" */
+        }
         S.st.n_clustered++;
         S.st.sum_len_queries += S.len[q];
+        if (taken[q]) continue;
         const int hit = check_one(&S, q, P, &nw, &hit_rep, &hit_iden, &hit_strand);
-        if (hit < 0) { free(member_count); goto done; }
+        if (hit < 0) { free(member_count); free(taken); goto done; }
         uint32_t cluster;
         if (hit) {
             cluster = hit_rep;
@@ -540,6 +571,7 @@ int pgxo_cluster_greedy(const uint8_t *residues, const uint64_t *offsets, uint32
         member_count[cluster]++;
     }
     free(member_count);
+    free(taken);
     S.st.n_clusters = S.n_reps;
     if (out_n_clusters) *out_n_clusters = S.n_reps;
     if (stats) *stats = S.st;

@@ -35,7 +35,9 @@ class ClusterParams(C.Structure):
                 # record-sharded multi-GPU mode (all zero / NULL = single GPU)
                 ('shard_index', C.c_int32), ('shard_count', C.c_int32),
                 ('exchange', EXCHANGE_FN), ('exchange_user', C.c_void_p), ('exchange_send', C.c_void_p),
-                ('exchange_recv', C.c_void_p)]
+                ('exchange_recv', C.c_void_p),
+                # cd-hit's memory-chunked rule: flush positions in the sorted list (NULL = unchunked)
+                ('chunk_boundaries', C.POINTER(C.c_uint32)), ('n_chunk_boundaries', C.c_uint32), ('reserved0', C.c_uint32)]
 
 
 STAT_FIELDS = ('n_input', 'n_clustered', 'n_clusters', 'sum_len_queries', 'sum_len_reps', 'rep_words',

@@ -755,6 +755,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         const bool rstrand = s >= half;
         const uint32_t ql = A.qlist ? A.qlist[rstrand ? s - half : s] - A.b0 : (rstrand ? s - half : s);
         if (A.shard_count > 1 && !A.qlist && ql % A.shard_count != A.shard_index) continue;   // another process's member
+        if (A.done[ql] == 2) continue;                    // placed by an earlier chunk's sweep (memory-chunked rule)
         const uint32_t q = A.b0 + ql;                     // the query (real sequence); candidates are r < q
         const uint32_t k = rstrand ? S.n_fwd + q : q;     // the strand walked
         const bool count_only = NEWONLY && A.done[ql];
@@ -1130,6 +1131,16 @@ __global__ __launch_bounds__(256) void window_init_kernel(uint32_t *__restrict__
     best[q] = kNoBest;
     if (rc_visits) rc_visits[q] = 0ull;
     if (q < 4 * window_cap / 8) reinterpret_cast<unsigned long long *>(flags)[q] = 0ull;
+}
+
+// Memory-chunked rule (pgx.h chunk_boundaries): window members that an earlier chunk's sweep has already placed are
+// ABSENT from everything that follows -- done = 2 (the filter skips them; they are never open), a best key that is
+// not "none". `taken` is the host's per-sequence flag array (page-locked, mapped), offset to the window.
+__global__ __launch_bounds__(256) void mark_absent_kernel(const uint8_t *__restrict__ taken, uint32_t nb,
+                                                         uint8_t *__restrict__ done,
+                                                         unsigned long long *__restrict__ best) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nb && taken[q]) { done[q] = 2; best[q] = 0ull; }
 }
 
 // record-sharded mode: element-wise minimum of the processes' best keys (gathered, one row per process)
@@ -1823,7 +1834,9 @@ struct Pinned {  // page-locked host staging buffer; bound to a context slot it 
     }
 };
 
-enum : uint8_t { ST_OPEN = 0, ST_MEMBER = 1, ST_REP = 2 };
+enum : uint8_t { ST_OPEN = 0, ST_MEMBER = 1, ST_REP = 2,
+                 ST_ABSENT = 3,    // memory-chunked rule: placed by an earlier chunk's sweep, not a member of this window any more
+                 ST_NONE = 4 };    // ... a sweep found no representative for it: it stays in the game
 
 #define LAUNCH_CHECK() PGX_HIP(hipGetLastError())
 
@@ -2155,11 +2168,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     double cur_frac = chunk_frac;
     uint64_t chunk_words = (uint64_t)(cur_frac * thr_frac * (double)n_codes);
     const bool chunking = chunk_words >= 16384;
-    auto form_window = [&](uint32_t b0, Chunks &C) -> uint32_t {
+    // cd-hit's memory-chunked rule (pgx.h): flush positions in the sorted list; a window never crosses one
+    std::vector<uint32_t> flush_at(P->chunk_boundaries, P->chunk_boundaries + (P->chunk_boundaries ? P->n_chunk_boundaries : 0u));
+    for (size_t i = 0; i < flush_at.size(); ++i)
+        PGX_REQUIRE(flush_at[i] > 0 && flush_at[i] < n && (i == 0 || flush_at[i] > flush_at[i - 1]),
+                    "chunk_boundaries must be strictly increasing positions in (0, number of clustered sequences)");
+    auto form_window = [&](uint32_t b0, Chunks &C, uint32_t limit) -> uint32_t {
         C.n = 1; C.begin[0] = 0;
         uint64_t in_chunk = 0;
         uint32_t q = 0;
-        for (; b0 + q < n && q < window_cap; ++q) {
+        for (; b0 + q < limit && q < window_cap; ++q) {
             const uint64_t w = h_len[b0 + q];
             if (chunking && in_chunk && in_chunk + w > chunk_words) {
                 if (C.n == kMaxChunks) break;
@@ -2175,16 +2193,20 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     uint32_t max_chunks = 1;   // the tag records are only as long as some window has chunks
     {
         Chunks C;
+        size_t nf = 0;
         for (uint32_t b0 = 0, nbw; b0 < n; b0 += nbw) {
-            nbw = form_window(b0, C);
+            while (nf < flush_at.size() && flush_at[nf] <= b0) ++nf;
+            nbw = form_window(b0, C, nf < flush_at.size() ? flush_at[nf] : n);
             max_window_words = std::max<uint64_t>(max_window_words, h_off[b0 + nbw] - h_off[b0]);
             max_chunks = std::max(max_chunks, C.n);
         }
+        if (!flush_at.empty())   // (the sweeps' windows start anywhere: no window holds more than the window_cap longest sequences)
+            max_window_words = std::max<uint64_t>(max_window_words, h_off[std::min(n, window_cap)]);
     }
     // The chunk volume adapts (cur_frac below), so later windows are not the ones of this scan: bound a window's words
     // independently of the partition -- no more than the window_cap longest sequences, no more than kMaxChunks
     // chunks of the largest volume (a chunk closes before it would exceed that, or holds one sequence).
-    if (chunking)
+    if (chunking && flush_at.empty())
         max_window_words = std::max<uint64_t>(max_window_words,
             std::min<uint64_t>(h_off[std::min(n, window_cap)], (uint64_t)kMaxChunks * std::max<uint64_t>(chunk_words, max_len)));
     PGX_REQUIRE(max_window_words < 0xFFFFFFF0ull, "window too large");
@@ -2413,8 +2435,30 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     std::vector<uint32_t> members;  // cluster -> members numbered so far
     uint64_t pending_words = 0;     // ... and its words
     Chunks chunks;
-    for (uint32_t b0 = 0, nb; b0 < n; b0 += nb) {
-        nb = form_window(b0, chunks);                      // queries of this window
+    // Memory-chunked rule: at a flush position every sequence not yet placed is compared with the index as it is
+    // (a SWEEP: windows over the rest of the list that run phase A only; a member with an accepted representative is
+    // placed there and then, the others stay in the game), then the index is emptied and clustering goes on.
+    Pinned<uint8_t> h_taken;        // per sorted sequence: placed by a sweep (the device reads it through the mapping)
+    h_taken.bind(ctx, 14);
+    if (!flush_at.empty()) { PGX_HIP(h_taken.reserve(n)); std::fill(h_taken.p, h_taken.p + n, (uint8_t)0); }
+    auto drain = [&]() -> int {     // nothing in flight, no bookkeeping pending
+        if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
+        PGX_HIP(hipStreamSynchronize(st_main));
+        PGX_HIP(hipStreamSynchronize(ctx->stream2));
+        return PGX_OK;
+    };
+    size_t next_flush = 0;
+    bool sweeping = false;
+    uint32_t sweep_at = 0;
+    for (uint32_t cursor = 0, nb = 0; cursor < n;) {
+        if (!sweeping && next_flush < flush_at.size() && cursor == flush_at[next_flush]) {
+            ++next_flush;
+            sweeping = true; sweep_at = cursor;
+            int rc = drain(); if (rc) return rc;
+        }
+        const bool sweep = sweeping;
+        const uint32_t b0 = sweep ? sweep_at : cursor;
+        nb = form_window(b0, chunks, sweep || next_flush >= flush_at.size() ? n : flush_at[next_flush]);   // queries of this window
         // this window's own state and stream (see `overlap`); the names below shadow the first set's
         const int set = overlap ? (int)(S.sweeps & 1u) : 0;
         const hipStream_t st = set ? ctx->stream2 : st_main;
@@ -2467,7 +2511,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         FA.qlist = nullptr; FA.d_nq = nullptr; FA.mark = nullptr; FA.count_visits = 1u;
 
         window_init_kernel<<<(window_cap + 255) / 256, 256, 0, st>>>(dc, d_best, both ? d_rcvis_p : nullptr, d_done, window_cap);
+        if (!flush_at.empty() && next_flush > 0)
+            mark_absent_kernel<<<(nb + 255) / 256, 256, 0, st>>>(h_taken.p + b0, nb, d_done, d_best);
         LAUNCH_CHECK();
+        // the host side of a window starts with the bookkeeping of the window before (deferred behind this window's
+        // first kernels), then the member states
+        auto begin_host_side = [&]() -> int {
+            if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
+            for (uint32_t q = 0; q < nb; ++q) status[q] = cluster_of[b0 + q] >= 0 ? ST_ABSENT : ST_OPEN;
+            return PGX_OK;
+        };
         // diag + align of a selection of pair records, enqueued on the stream
         auto evaluate = [&](Pair *pairs, const PairSel &sel, unsigned long long *best_arr, uint32_t grid_hint) -> int {
             const uint32_t dg = grid_hint ? std::min(diag_grid, grid_hint) : diag_grid;
@@ -2555,6 +2608,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // index, and the pass against them assigns most of the remaining members; a second round confirms
         // the members the first round's representatives rejected (the outliers of their families). All on
         // the device: the host learns the outcome with the first block's results.
+        if (sweep) { int rc = begin_host_side(); if (rc) return rc; }
+        if (!sweep) {   // ---- discovery rounds and blocks (a sweep window has neither: nothing is appended) ----
         if (overlap && S.sweeps > 1)   // from here on the index is written: the window before must have closed
             PGX_HIP(hipStreamWaitEvent(st, ev.post[set ^ 1], 0));
         static const int n_disc = std::getenv("PGX_ROUNDS") ? std::atoi(std::getenv("PGX_ROUNDS")) : kDiscoveryRounds;
@@ -2637,8 +2692,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             if (first_block) {
                 // everything up to here was enqueued without looking at results: the previous window's
                 // bookkeeping runs now, behind that work, and only then is the member state reset
-                if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
-                for (uint32_t q = 0; q < nb; ++q) status[q] = ST_OPEN;
+                int rc = begin_host_side(); if (rc) return rc;
             }
             PGX_HIP(spin_sync(st));
             if (h_cnt.p[C_ERR]) {
@@ -2793,7 +2847,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             }
             if (n_open == n_blk) break;  // that was the last block
         }
-        if (chunking) {   // the discovery chunks of the windows to come (see chunk_frac)
+        }   // (!sweep)
+        if (chunking && !sweep) {   // the discovery chunks of the windows to come (see chunk_frac)
             const uint64_t blk = n_blocks - blocks_before;
             if (blk >= 3) cur_frac = std::max(0.1, cur_frac * 0.5);
             else if (blk <= 1) cur_frac = std::min(chunk_frac, cur_frac * 1.5);
@@ -2850,7 +2905,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         const auto t_c0 = std::chrono::steady_clock::now();
         {
             pending_words = window_words;
-            deferred = [&, b0, nb, nW, closed, p_best = &h_best_w, p_hW = &hW_w]() mutable -> int {
+            deferred = [&, b0, nb, nW, sweep, closed, p_best = &h_best_w, p_hW = &hW_w]() mutable -> int {
                 if (overlap) { int rc = closed(nW); if (rc) return rc; }
                 const Pair *pW = p_hW->p;
                 pending_words = 0;
@@ -2858,14 +2913,18 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 for (uint32_t q = 0; q < nb; ++q) {
                     if (status[q] != ST_OPEN) continue;
                     const unsigned long long key = p_best->p[q];
-                    if (key == kNoBest) { pgx_set_error("pgx_cluster_greedy: unresolved member after the last block"); return PGX_ERR_INTERNAL; }
+                    if (key == kNoBest) {
+                        if (sweep) { status[q] = ST_NONE; continue; }   // no representative in the table being dropped
+                        pgx_set_error("pgx_cluster_greedy: unresolved member after the last block"); return PGX_ERR_INTERNAL;
+                    }
                     status[q] = ST_MEMBER;
                     winner_key[q] = key;
                     strand_of[b0 + q] = (uint8_t)(key >> 63);
+                    if (sweep) h_taken.p[b0 + q] = 1;
                 }
                 if (both)  // reverse-strand word walks happen only for queries the forward strand did not place
                     for (uint32_t q = 0; q < nb; ++q)
-                        if (status[q] == ST_REP || (winner_key[q] >> 63)) visits_rc += h_rcvis.p[q];
+                        if (status[q] == ST_REP || status[q] == ST_NONE || (status[q] == ST_MEMBER && (winner_key[q] >> 63))) visits_rc += h_rcvis.p[q];
                 // new representatives are numbered in sequence order
                 for (uint32_t q = 0; q < nb; ++q)
                     if (status[q] == ST_REP) {
@@ -2884,7 +2943,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                     if ((p.flags & F_TOO_BIG) && (p.flags & F_DIAG_PASS)) { fits = false; continue; }
                     const unsigned long long key = pair_key(p);
                     // the one-by-one pass examines candidates in key order up to and including the winner
-                    if (status[q] == ST_REP || key <= winner_key[q]) {
+                    if (status[q] == ST_REP || status[q] == ST_NONE || key <= winner_key[q]) {
                         S.filter_pairs++;
                         if ((p.flags & (F_DIAG_PASS | F_BAND_OK)) == (F_DIAG_PASS | F_BAND_OK)) {
                             S.aligned_pairs++;
@@ -2901,6 +2960,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 // the window's outputs, in the caller's order; member numbers follow the sorted order (A.3)
                 members.resize(rep_seq.size(), 0u);
                 for (uint32_t q = 0; q < nb; ++q) {
+                    if (status[q] == ST_ABSENT || status[q] == ST_NONE) continue;   // (written when placed / not placed yet)
                     const uint32_t k = b0 + q, o = order[k];
                     const int32_t c = cluster_of[k];
                     out_cluster[o] = c;
@@ -2921,6 +2981,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                     (unsigned long long)S.sweeps, b0, h_len[b0], h_len[b0 + nb - 1],
                     (unsigned long long)(n_blocks - blocks_before), rep_seq.size() - n_reps, rep_seq.size(), nW,
                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sweep0).count());
+        if (!sweep) { cursor += nb; continue; }
+        sweep_at += nb;
+        if (sweep_at >= n) {   // the sweep is complete: the index is emptied, clustering goes on with what is left
+            int rc = drain(); if (rc) return rc;
+            PGX_HIP(hipMemsetAsync(d_lines.p, 0, (size_t)n_codes * sizeof(IndexLine), st_main));
+            const uint32_t one = 1u;
+            PGX_HIP(hipMemcpyAsync(d_idx.p, &one, 4, hipMemcpyHostToDevice, st_main));
+            PGX_HIP(hipStreamSynchronize(st_main));
+            sweeping = false;
+        }
     }
     if (deferred) { int rc = deferred(); deferred = nullptr; if (rc) return rc; }
     if (trace)

@@ -26,11 +26,11 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, 'pangenomix_amd', 'libpgx.so'))
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert _native.lib().pgx_version() == 200
+    assert _native.lib().pgx_version() == 300
 
 
 def test_struct_layouts_match_the_header():
-    assert ctypes.sizeof(_native.ClusterParams) == 6 * 4 + 3 * 8 + 2 * 4 + 4 * 8
+    assert ctypes.sizeof(_native.ClusterParams) == 6 * 4 + 3 * 8 + 2 * 4 + 4 * 8 + 8 + 2 * 4
     assert ctypes.sizeof(_native.ClusterStats) == 16 * 8
     assert ctypes.sizeof(_native.DeviceInfo) == 64 + 32 + 4 * 4 + 8 + 2 * 4
 

@@ -186,3 +186,77 @@ def test_nt_clstr_grammar(tmp_path):
     path = str(tmp_path / 'x.clstr')
     cluster.write_clstr(path, ['h0', 'h1'], np.diff(off.astype(np.int64)), cl, mem, iden, strand, nucleotide=True)
     assert open(path).read() == '>Cluster 0\n0\t120nt, >h0... *\n1\t110nt, >h1... at -/100.00%\n'
+
+
+def _chunk_case(seed):
+    """A (300), B (290), C (280): A and B are too far apart to cluster (about 76 % identical), C is 88 % identical
+    to both. Unchunked, C joins whichever of A, B comes first in its candidate order (smallest shared word code,
+    then index); with the table flushed after A, the sweep over the remaining sequences gives C to A."""
+    rng = np.random.default_rng(seed)
+    x = rand_seq(rng, 300)
+    pos = rng.permutation(280)
+    a = list(x)
+    b = list(x[:290])
+    for p_ in pos[:36]:
+        a[p_] = AA[(AA.index(a[p_]) + 1 + int(rng.integers(0, 19))) % 20]
+    for p_ in pos[36:72]:
+        b[p_] = AA[(AA.index(b[p_]) + 1 + int(rng.integers(0, 19))) % 20]
+    return [''.join(a), ''.join(b), x[:280]]
+
+
+def test_memory_chunked_rule_changes_a_membership():
+    """SURVEY A.6 (cd-hit's -M chunking, an optional emulation: params.chunk_boundaries). Known answer: a case where
+    the unchunked winner is the LATER representative, and the flush after the first sequence hands the member to
+    the earlier one; boundaries that cut nothing change nothing."""
+    found = None
+    for seed in range(40):
+        seqs = _chunk_case(seed)
+        cl = run(seqs)[0]
+        if cl.tolist() == [0, 1, 1]:
+            found = seqs
+            break
+    assert found is not None, 'no seed puts B first in C\'s candidate order'
+    res, off = pack(found)
+    p, keep = cluster.with_chunk_boundaries(params(), [1])
+    cl, mem, iden, _, nc, st = oracle.cluster_greedy(res, off, p)
+    assert cl.tolist() == [0, 1, 0] and mem.tolist() == [0, 0, 1] and nc == 2
+    assert iden[2] >= np.float32(0.8) and iden[1] == 0
+    # B was compared with A's table in the sweep and rejected, then again (empty table) as a query of its own chunk
+    assert st['aligned_pairs'] >= 2 and st['n_clustered'] == 3
+    # a boundary after B as well: C already went to A in the first sweep
+    p2, keep2 = cluster.with_chunk_boundaries(params(), [1, 2])
+    assert oracle.cluster_greedy(res, off, p2)[0].tolist() == [0, 1, 0]
+    # a flush between B and C only: the table still holds A and B when C... no: it is empty -- C was swept with {A, B}
+    p3, keep3 = cluster.with_chunk_boundaries(params(), [2])
+    assert oracle.cluster_greedy(res, off, p3)[0].tolist() == [0, 1, 1]
+
+
+def test_chunk_boundaries_are_validated():
+    res, off = pack(_chunk_case(0))
+    for bad in ([0], [3], [2, 2], [2, 1]):
+        b = np.array(bad, dtype=np.uint32)
+        p = params()
+        import ctypes as C
+        p.chunk_boundaries = b.ctypes.data_as(C.POINTER(C.c_uint32))
+        p.n_chunk_boundaries = b.size
+        with pytest.raises(RuntimeError):
+            oracle.cluster_greedy(res, off, p)
+
+
+def test_chunked_rule_on_a_synthetic_set_keeps_the_invariants():
+    """Every member still meets the identity threshold against its representative, representatives are the longest
+    of their clusters, and a sequence placed by a sweep belongs to a representative of an EARLIER chunk."""
+    res, off, _ = synth.protein_set('tiny').nr_arrays()
+    base = oracle.cluster_greedy(res, off, params())
+    n = base[5]['n_clustered']
+    bd = [n // 4, n // 2]
+    p, keep = cluster.with_chunk_boundaries(params(), bd)
+    cl, mem, iden, _, nc, st = oracle.cluster_greedy(res, off, p)
+    assert nc >= base[4]                                   # a flushed table can only miss representatives
+    assert (iden[mem > 0] >= np.float32(0.8)).all() and (iden[mem == 0] == 0).all()
+    # (a swept sequence meets the flushed table once and never the later representatives: no more visits than unchunked)
+    assert st['n_clustered'] == n and st['posting_visits'] <= base[5]['posting_visits']
+    lens = np.diff(off.astype(np.int64))
+    rep_of = np.full(nc, -1, dtype=np.int64)
+    rep_of[cl[mem == 0]] = np.flatnonzero(mem == 0)
+    assert (lens[rep_of[cl[cl >= 0]]] >= lens[cl >= 0]).all()
