@@ -188,8 +188,7 @@ def main():
     n_nr = off.size - 1
     params = base_params = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
     if sharded:   # every rank holds the same sequences; window member i belongs to rank i % world
-        send = torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device=dev)
-        recv = torch.empty((world, cluster.EXCHANGE_KEYS), dtype=torch.int64, device=dev)
+        send, recv = cluster.exchange_buffers(world, dev)
         params, _keep = cluster.shard_params(params, rank, world, send, recv, cluster.group_all_gather(dist.group.WORLD))
     d_res = torch.from_numpy(res.copy()).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)

@@ -37,6 +37,8 @@ extern "C" {
 
 #define PGX_VERSION 300 /* 0.3.0 */
 #define PGX_EXCHANGE_KEYS 65536u /* keys per process and exchange = the largest window */
+#define PGX_EXCHANGE_WORDS (PGX_EXCHANGE_KEYS + 8u) /* uint64 per process and exchange: the keys + the error word (+ padding) */
+#define PGX_EXCHANGE_SLOTS 2u    /* windows in flight, each with its own send / receive buffers */
 
 typedef enum pgx_status {
     PGX_OK = 0,
@@ -176,15 +178,18 @@ typedef struct pgx_cluster_params {
      * partial per process: sum the counters / take the maximum of out_identity over the processes
      * (pangenomix_amd/cluster.py does). */
     int32_t shard_index, shard_count;
-    /* All-gather of PGX_EXCHANGE_KEYS uint64 per process: exchange_send of every process p into
-     * exchange_recv[p * PGX_EXCHANGE_KEYS ...] of all. The callback ENQUEUES the collective on
-     * `stream` (the stream the library works on) and returns without waiting: e.g.
-     * torch.distributed.all_gather_into_tensor under torch.cuda.ExternalStream(stream) = RCCL over
-     * xGMI with the nccl backend. 0 = success. Called a few times per window. */
-    int (*exchange)(void *user, void *stream);
+    /* All-gather of PGX_EXCHANGE_WORDS uint64 per process: slot `slot` of exchange_send of every process p into
+     * exchange_recv[slot][p][...] of all. Two consecutive windows are in flight on two streams, each with its own
+     * slot (send: [PGX_EXCHANGE_SLOTS][PGX_EXCHANGE_WORDS], recv: [PGX_EXCHANGE_SLOTS][shard_count][PGX_EXCHANGE_WORDS]).
+     * The callback ENQUEUES the collective on `stream` (the stream that window works on) and returns without
+     * waiting: e.g. torch.distributed.all_gather_into_tensor under torch.cuda.ExternalStream(stream) = RCCL over
+     * xGMI with the nccl backend. Every process issues its calls in the same order. 0 = success. A few calls per
+     * window. The word behind the keys carries the process's error state: a capacity failure on one process makes
+     * every process return PGX_ERR_CAPACITY at the same point (nobody is left waiting in a collective). */
+    int (*exchange)(void *user, void *stream, int slot);
     void *exchange_user;
-    void *exchange_send;    /* device, PGX_EXCHANGE_KEYS uint64 (the caller's allocation, so that */
-    void *exchange_recv;    /* device, shard_count * PGX_EXCHANGE_KEYS uint64   its collective library can address it) */
+    void *exchange_send;    /* device (the caller's allocation, so that its collective library can address it) */
+    void *exchange_recv;    /* device */
     /* cd-hit's MEMORY-CHUNKED rule, optional emulation. cd-hit bounds its word table by what is left
      * of `-M` (default 800 MB; the reference's call passes no -M, pangenome.py:444-447): when the table is full,
      * every sequence not yet clustered is compared with the current table at once (and joins the first

@@ -23,9 +23,11 @@ class DeviceInfo(C.Structure):
                 ('clock_khz', C.c_int32), ('reserved', C.c_int32)]
 
 
-# int (*exchange)(void *user, void *stream): enqueue the all-gather of the window's best keys (pgx.h)
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
-EXCHANGE_KEYS = 65536   # PGX_EXCHANGE_KEYS
+# int (*exchange)(void *user, void *stream, int slot): enqueue the all-gather of a window's best keys (pgx.h)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+EXCHANGE_KEYS = 65536                  # PGX_EXCHANGE_KEYS
+EXCHANGE_WORDS = EXCHANGE_KEYS + 8     # PGX_EXCHANGE_WORDS: the keys + the error word (+ padding)
+EXCHANGE_SLOTS = 2                     # PGX_EXCHANGE_SLOTS: windows in flight
 
 
 class ClusterParams(C.Structure):

@@ -74,6 +74,14 @@ constexpr int kMaxBand = 64;
 __constant__ int8_t kBlosum62_dev[kNAA1 * kNAA1] = PGXC_BLOSUM62_FLAT;
 
 enum : uint32_t { F_DIAG_PASS = 1, F_BAND_OK = 2, F_ACCEPT = 4, F_TOO_BIG = 8, F_EVAL = 16, F_ALIGNED = 32 };
+// bits of a window's error word (counter C_ERR). In the record-sharded mode the word travels with every exchange of
+// the best keys and is OR-ed over the processes, so that every process sees the same word at the same point of the
+// window loop and all of them leave together.
+enum : uint32_t { E_TOUCHED = 1,    // an append round set more entries aside than the scratch list holds
+                  E_POOL = 2,       // the overflow pool of the word index is full
+                  E_TABLE = 4,      // the filter's exact table overflowed at the finest residue class
+                  E_BAND = 8,       // a pair that passed the diagonal test has a band wider than kMaxBand
+                  E_PAIRS = 16 };   // the window's candidate pair buffer overflowed
 
 struct Pair {           // one (query, representative) candidate
     uint32_t q;         // sorted sequence index of the query
@@ -98,6 +106,7 @@ struct PairSel {
     uint8_t *accepted_out;
     uint32_t b0;
     uint32_t skip_evaluated;  // leave pairs alone that an earlier round has been through
+    uint32_t all_if_le;       // a selection of at most this many pairs ignores only_a / only_not_b: every pair is taken
 };
 __device__ __forceinline__ uint32_t sel_count(const PairSel &s) {
     if (s.list) return s.n_list;
@@ -385,12 +394,21 @@ __device__ __forceinline__ uint32_t line_len_prev(const IndexLine &L) { return ~
 // entries that fall behind the line are set aside (code, position, entry) and placed by two short passes
 // over just those: room first, then the entries. [Three passes over all words -- count, grow, write --
 // before: 11.2 -> 7.5 ms per step on cfg-3s.]
+// The round's map of touched codes has one bit per code AND SEGMENT of the window (kSegs equal ranges of member
+// positions; the kSegs bits of a code are adjacent: eight codes per 32-bit word): bit j of a code is set when one of
+// the round's representatives in segments 0..j has the word, and a member of segment j probes bit j. A member only
+// ever visits entries of representatives BEFORE it, all of which are in its own segment or an earlier one; with one
+// bit per code half of the marked words of a member (a line read each) lead to later representatives only -- with
+// kSegs bits an eighth. Setting the bits of segments seg..kSegs-1 is ONE atomicOr, probing one load, as before.
+// [filter<new> 31.2 -> 22.1 ms per step on cfg-3s together with the 512-slot direct table.]
+constexpr uint32_t kSegs = 4;
+__device__ __forceinline__ uint32_t seg_of(uint32_t ql, uint32_t nbq) { return (uint32_t)(((uint64_t)ql * kSegs) / nbq); }
 struct Deferred { uint32_t code, pos, entry, pad; };
 __global__ __launch_bounds__(256) void index_append_kernel(DevSeqs S, const uint32_t *__restrict__ list,
                                                           const uint32_t *__restrict__ d_lo,
                                                           const uint32_t *__restrict__ d_hi,
                                                           IndexLine *__restrict__ lines, uint32_t epoch,
-                                                          uint32_t *__restrict__ newbits,
+                                                          uint32_t *__restrict__ newbits, uint32_t b0, uint32_t nbq,
                                                           Deferred *__restrict__ deferred,
                                                           uint32_t *__restrict__ n_deferred, uint32_t deferred_cap,
                                                           uint32_t *__restrict__ err) {
@@ -398,17 +416,21 @@ __global__ __launch_bounds__(256) void index_append_kernel(DevSeqs S, const uint
     for (uint32_t w = lo + blockIdx.x * 4 + (threadIdx.x >> 6); w < hi; w += gridDim.x * 4) {
         const uint32_t k = list[w];
         const uint64_t o = S.off[k];
-        const uint32_t nw = S.wcnt[k];
+        const uint32_t nw = S.wcnt[k], seg = seg_of(k - b0, nbq);
         for (uint32_t i = lane; i < nw; i += 64) {
             const uint32_t code = S.wcode[o + i], m = S.wmult[o + i];
             IndexLine &L = lines[code];
             const uint32_t pos = atomicAdd(&L.len, 1u);
             atomicMax(&L.round, ((unsigned long long)epoch << 32) | (uint32_t)~pos);
-            if (!((newbits[code >> 5] >> (code & 31u)) & 1u)) atomicOr(&newbits[code >> 5], 1u << (code & 31u));
+            {
+                const uint32_t mask = ((0xFu << seg) & 0xFu) << ((code & 7u) * kSegs);
+                uint32_t *bw = newbits + (code >> 3);
+                if ((*bw & mask) != mask) atomicOr(bw, mask);
+            }
             const uint32_t entry = k | ((m < fmax ? m : fmax) << S.mshift);
             if (pos < kInline) { L.e[pos] = entry; continue; }
             const uint32_t t = atomicAdd(n_deferred, 1u);
-            if (t < deferred_cap) deferred[t] = Deferred{code, pos, entry, 0u}; else *err = 1u;
+            if (t < deferred_cap) deferred[t] = Deferred{code, pos, entry, 0u}; else atomicOr(err, (uint32_t)E_TOUCHED);
         }
     }
 }
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(256) void index_grow_kernel(IndexLine *__restrict__
         if (novf <= cap) continue;
         const uint32_t ncap = max(2u * novf, 32u);
         const uint32_t idx = atomicAdd(pool_used, ncap + 1u);
-        if ((uint64_t)idx + ncap + 1u > pool_cap) { *err = 2u; continue; }
+        if ((uint64_t)idx + ncap + 1u > pool_cap) { atomicOr(err, (uint32_t)E_POOL); continue; }
         pool[idx] = ncap;
         const uint32_t before = line_len_prev(L);
         const uint32_t have = before > kInline ? before - kInline : 0u;
@@ -477,7 +499,7 @@ constexpr unsigned long long kNoBest = ~0ull;
 struct FilterArgs {
     const IndexLine *lines;
     const uint32_t *pool;
-    const uint32_t *newbits;
+    const uint32_t *newbits;                  // NEWONLY: kSegs bits per code (see index_append_kernel)
     const uint32_t *d_round_lo, *d_round_hi;  // NEWONLY: the round's representatives list[lo, hi): nothing to do when empty
     uint32_t epoch;
     uint32_t b0, nbq, ns;
@@ -555,17 +577,20 @@ struct FTimer { __device__ void start() {} };
 // of them, so that the exact pass need not walk the word list again
 struct Marked { uint32_t code, mult, n; bool complete; };
 
-template <bool NEWONLY, bool PASS2, int FH>
+template <bool NEWONLY, bool PASS2, int FH, int FB>
 __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &A, const FilterWave &W, uint32_t lane,
                                             uint64_t o, uint32_t nw, uint32_t q, uint32_t thr, bool count_only,
                                             uint32_t class_k, uint32_t class_j, uint32_t &visits, bool &hot,
-                                            bool &full, Marked &M, FTimer &ft, bool redo = false) {
+                                            bool &full, Marked &M, FTimer &ft, uint32_t seg, bool redo = false) {
     const uint32_t rmask = entry_rmask(S), fmax = entry_fmax(S);
-    // NEWONLY, first walk: when all the marked words fit one slab (the usual case: a round adds few entries to a
-    // query's lists), the representatives met go straight into the exact table -- no bucket pass, no second walk.
-    // If the table overflows, the walk is redone (`redo`) on the marked words with the buckets, visits not counted
-    // again, and the exact passes per residue class follow as for any other walk.
-    bool direct = false;
+    // NEWONLY, first walk: the representatives met go straight into the exact table -- no bucket pass, no second
+    // walk (a round adds few entries to a query's lists; the table of these kernels has 512 slots, so a member of up
+    // to ~1500 residues fits even when every marked word leads to another representative). If the table overflows,
+    // the walk is redone (`redo`) with the buckets, visits not counted again, and the exact passes per residue
+    // class follow as for any other walk. [Direct only for members whose marked words fit ONE slab, 256 slots,
+    // before: the quarter of the members beyond that paid a bucket walk and a whole second walk -- a third of the
+    // kernel's time.]
+    const bool direct = NEWONLY && !PASS2 && !redo;
     auto entry_visit = [&](uint32_t entry, uint32_t code, uint32_t mq) {
         const uint32_t r = entry & rmask;
         if (r >= q) return;                      // only representatives created before the query
@@ -575,7 +600,9 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             if (mr == fmax) mr = word_mult_of(S.wcode, S.wmult, S.off[r], S.wcnt[r], code);
             c = mr < mq ? mr : mq;
         }
-        const uint32_t b = (r * 0x9E3779B1u) >> 22;   // 10 bits
+        constexpr int kFBBits = FB == 1024 ? 10 : (FB == 512 ? 9 : 8);
+        static_assert(FB == (1 << kFBBits), "bucket count");
+        const uint32_t b = (r * 0x9E3779B1u) >> (32 - kFBBits);
         if (!PASS2) {
             if (!redo) ++visits;
             if (count_only) return;
@@ -672,14 +699,14 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
 #pragma unroll
         for (int j = 0; j < 4; ++j) load_word(base + 64u * j, c[j], m[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { nbw[j] = 0u; if (m[j]) nbw[j] = A.newbits[c[j] >> 5]; }
+        for (int j = 0; j < 4; ++j) { nbw[j] = 0u; if (m[j]) nbw[j] = A.newbits[c[j] >> 3]; }
 #ifdef PGX_FTIME
         if (!PASS2) { if (__ballot(nbw[0] == 0x12345u && nbw[3] == 0x54321u) == ~0ull) return; FT_LAP(ft, 1); }   // (waits for the probes)
 #endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (base + 64u * j >= nw) break;
-            const bool live = (nbw[j] >> (c[j] & 31u)) & 1u;
+            const bool live = (nbw[j] >> ((c[j] & 7u) * kSegs + seg)) & 1u;
             const unsigned long long mask = __ballot(live);
             if (!mask) continue;
             const uint32_t n = (uint32_t)__popcll(mask);
@@ -699,7 +726,6 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
         }
     }
     if (!PASS2) FT_LAP(ft, 2);
-    direct = !PASS2 && !flushed;
     if (np) slab(pc, pm, lane < np);
     if (!PASS2) { M.code = pc; M.mult = pm; M.n = np; M.complete = !flushed; FT_LAP(ft, 3); }
     else FT_LAP(ft, 6);
@@ -707,8 +733,11 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
 
 template <bool NT, bool NEWONLY>
 __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][kFB];
-    constexpr int FH = NT ? kFHNt : kFH;
+    // passes over a round's entries (proteins): the exact table first (512 slots), the buckets only for what
+    // overflows it (256 are enough there: thresholds of long members are far above what chance hits add up to)
+    constexpr int FB = NEWONLY && !NT ? 256 : kFB;
+    constexpr int FH = NT ? kFHNt : (NEWONLY ? 2 * kFH : kFH);
+    __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][FB];
     __shared__ uint32_t s_hrep[4][FH], s_hcnt[4][FH], s_hminc[4][FH];
     __shared__ uint4 s_lq[4][64];
     __shared__ uint32_t s_pref[4][64];
@@ -722,7 +751,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     __syncthreads();
     const FilterWave W{s_bucket[wave], s_hrep[wave], s_hcnt[wave], s_hminc[wave], s_lq[wave], s_pref[wave]};
     uint2 *work = s_work[wave];
-    for (uint32_t i = lane; i < kFB; i += 64) W.bucket[i] = 0u;
+    for (uint32_t i = lane; i < (uint32_t)FB; i += 64) W.bucket[i] = 0u;
     for (uint32_t i = lane; i < (uint32_t)FH; i += 64) { W.hrep[i] = kEmpty; W.hcnt[i] = 0u; W.hminc[i] = kSentinel; }
     wave_lds_sync();
 
@@ -759,6 +788,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         const uint32_t q = A.b0 + ql;                     // the query (real sequence); candidates are r < q
         const uint32_t k = rstrand ? S.n_fwd + q : q;     // the strand walked
         const bool count_only = NEWONLY && A.done[ql];
+        const uint32_t seg = NEWONLY ? seg_of(ql, A.nbq) : 0u;
         const int32_t t0 = A.req_aan[q];
         const uint32_t thr = t0 > 1 ? (uint32_t)t0 : 1u;
         const uint64_t o = S.off[k];
@@ -770,7 +800,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
         if (__ballot(nw == 0xFFFFFFFFu && thr == 0u) == ~0ull) return;   // (consumes the prologue loads)
         FT_LAP(ft, 0);
 #endif
-        filter_walk<NEWONLY, false, FH>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full, marked, ft);
+        filter_walk<NEWONLY, false, FH, FB>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full, marked, ft, seg);
         wave_lds_sync();
         for (int d = 32; d > 0; d >>= 1) visits += __shfl_xor(visits, d);
         FT_LAP(ft, 4);
@@ -807,7 +837,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
             }
             wave_lds_sync();
         };
-        bool direct_done = NEWONLY && marked.complete && !count_only;   // (wave-uniform)
+        bool direct_done = NEWONLY && !count_only;   // (wave-uniform)
         if (direct_done && visits) {
             if (__ballot(full)) {
 #ifdef PGX_FTIME
@@ -815,7 +845,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
 #endif
                 emit_table(true);
                 full = false; hot = false;
-                filter_walk<NEWONLY, false, FH>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full, marked, ft, true);
+                filter_walk<NEWONLY, false, FH, FB>(S, A, W, lane, o, nw, q, thr, count_only, 1u, 0u, visits, hot, full, marked, ft, seg, true);
                 wave_lds_sync();
                 direct_done = false;
             } else {
@@ -839,12 +869,12 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
                 --n_work;
                 full = false;
                 FT_LAP(ft, 5);
-                filter_walk<NEWONLY, true, FH>(S, A, W, lane, o, nw, q, thr, false, cls.x, cls.y, visits, hot, full, marked, ft);
+                filter_walk<NEWONLY, true, FH, FB>(S, A, W, lane, o, nw, q, thr, false, cls.x, cls.y, visits, hot, full, marked, ft, seg);
                 wave_lds_sync();
                 FT_LAP(ft, 7);
                 const bool over = __ballot(full) != 0ull;
                 if (over) {
-                    if (cls.x >= (1u << 20) || n_work + 4 > (uint32_t)kFWork) { if (lane == 0) *A.err = 3u; n_work = 0; }
+                    if (cls.x >= (1u << 20) || n_work + 4 > (uint32_t)kFWork) { if (lane == 0) atomicOr(A.err, (uint32_t)E_TABLE); n_work = 0; }
                     else {
                         if (lane < 4) work[n_work + lane] = make_uint2(cls.x * 4u, cls.y + lane * cls.x);
                         n_work += 4;
@@ -855,7 +885,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
             }
         }
         if (visits && !count_only && !direct_done) {
-            for (uint32_t i = lane * 4; i < (uint32_t)kFB; i += 256) *reinterpret_cast<uint4 *>(&W.bucket[i]) = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t i = lane * 4; i < (uint32_t)FB; i += 256) *reinterpret_cast<uint4 *>(&W.bucket[i]) = make_uint4(0u, 0u, 0u, 0u);
             wave_lds_sync();
         }
         FT_LAP(ft, 9);
@@ -1144,14 +1174,26 @@ __global__ __launch_bounds__(256) void mark_absent_kernel(const uint8_t *__restr
 }
 
 // record-sharded mode: element-wise minimum of the processes' best keys (gathered, one row per process)
+// (the error words of the processes, one behind each row's keys, are OR-ed into this window's C_ERR)
 __global__ __launch_bounds__(256) void min_rows_kernel(const unsigned long long *__restrict__ rows, uint32_t n_rows,
                                                       uint32_t row_stride, uint32_t n,
-                                                      unsigned long long *__restrict__ out) {
+                                                      unsigned long long *__restrict__ out, uint32_t *__restrict__ err) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        uint32_t e = 0;
+        for (uint32_t r = 0; r < n_rows; ++r) e |= (uint32_t)rows[(size_t)r * row_stride + PGX_EXCHANGE_KEYS];
+        if (e) atomicOr(err, e);
+    }
     if (i >= n) return;
     unsigned long long m = rows[i];
     for (uint32_t r = 1; r < n_rows; ++r) { const unsigned long long v = rows[(size_t)r * row_stride + i]; m = v < m ? v : m; }
     out[i] = m;
+}
+
+// before an exchange: this process's error word goes behind its keys
+__global__ void exchange_prepare_kernel(const uint32_t *__restrict__ counters, uint32_t pair_cap,
+                                        unsigned long long *__restrict__ send, uint32_t inject) {
+    send[PGX_EXCHANGE_KEYS] = counters[C_ERR] | (counters[C_NW] > pair_cap ? (uint32_t)E_PAIRS : 0u) | inject;
 }
 
 // One round trip's worth of results written straight into page-locked host memory: each
@@ -1312,7 +1354,8 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
                                                  const int32_t *__restrict__ req_aa1,
                                                  const int32_t *__restrict__ req_aas, int band_width,
                                                  double cluster_thd, uint32_t *__restrict__ gscratch,
-                                                 uint32_t gscratch_stride, uint32_t *__restrict__ n_wide) {
+                                                 uint32_t gscratch_stride, uint32_t *__restrict__ n_wide,
+                                                 uint32_t *__restrict__ err) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_wide = 0u;   // (pairs that the 16-lane aligner, which runs next, leaves to align_kernel)
     __shared__ uint32_t diag[CAP];
     __shared__ uint32_t taap[kNAA1 * kNAA1 + 7];
@@ -1324,8 +1367,10 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
     for (uint32_t w = blockIdx.x; w < np; w += gridDim.x) {
         const uint32_t p = sel_pair(sel, w);
         const Pair pr = pairs[p];
-        if (sel.only_a && !sel.only_a[pr.r - sel.b0]) continue;  // block-uniform
-        if (sel.only_not_b && sel.only_not_b[pr.r - sel.b0]) continue;
+        if (np > sel.all_if_le) {   // (a few hundred pairs cost one dependent alignment chain whether all or some are taken)
+            if (sel.only_a && !sel.only_a[pr.r - sel.b0]) continue;  // block-uniform
+            if (sel.only_not_b && sel.only_not_b[pr.r - sel.b0]) continue;
+        }
         if (sel.skip_evaluated && (pr.flags & F_EVAL)) continue;
         const uint32_t k1 = pr.q, k2 = rep_seq ? rep_seq[pr.r] : pr.r;
         const uint32_t k1r = real_of(S, k1);  // thresholds are the query's, whichever strand
@@ -1389,7 +1434,7 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
             uint32_t fl = F_EVAL;
             if (best_sum >= req_aas[k1r]) fl |= F_DIAG_PASS;
             if (!(br >= len2 || bl <= -len1 || bl > br)) fl |= F_BAND_OK;
-            if (br - bl + 1 > kMaxBand) fl |= F_TOO_BIG;
+            if (br - bl + 1 > kMaxBand) { fl |= F_TOO_BIG; if (fl & F_DIAG_PASS) atomicOr(err, (uint32_t)E_BAND); }
             pairs[p].best_sum = best_sum; pairs[p].band_left = bl; pairs[p].band_center = bc;
             pairs[p].band_right = br; pairs[p].flags = fl;
         }
@@ -2001,7 +2046,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 "shard_index must be in [0, shard_count)");
     PGX_REQUIRE(P->shard_count <= 1 || P->exchange, "shard_count > 1 needs an exchange callback");
     PGX_REQUIRE(!P->exchange || (P->exchange_send && P->exchange_recv),
-                "the exchange callback needs exchange_send / exchange_recv (PGX_EXCHANGE_KEYS uint64 per process, device memory)");
+                "the exchange callback needs exchange_send / exchange_recv (2 slots of PGX_EXCHANGE_WORDS uint64 per process, device memory)");
     PGX_HIP(hipSetDevice(ctx->device_id));
     hipStream_t st = (hipStream_t)stream_;
     const auto t_call0 = std::chrono::steady_clock::now();
@@ -2245,7 +2290,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_lines.alloc((size_t)n_codes * sizeof(IndexLine)));
     PGX_HIP(hipMemsetAsync(d_lines.p, 0, (size_t)n_codes * sizeof(IndexLine), st));
     PGX_HIP(d_idx.alloc(16));
-    PGX_HIP(d_newbits.alloc(((size_t)n_codes / 32 + 2) * 4 + 16));
+    static_assert(kSegs == 4, "eight codes per word of the round's map");
+    const uint32_t bm_words = (n_codes / 8 + 2 + 3) & ~3u;   // words of the round's map of touched codes
+    PGX_HIP(d_newbits.alloc((size_t)bm_words * 4 + 16));
     PGX_HIP(d_touched.alloc((max_window_words + 16) * sizeof(Deferred)));   // entries set aside by an append round
     if (chunking && n > window_cap / 2) max_chunks = kMaxChunks;   // (smaller chunks later may need all of them)
     uint32_t tag_stride = 1;   // first-open tags: one record of tag_stride >= max_chunks words per code
@@ -2271,11 +2318,13 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     // pair records and host copies (two sets, used alternately); window w+1 starts when the index of window w is
     // final (event after its last strike-out) and appends to the index only after window w's close (second event).
     // A few hundred pairs per evaluation keep a 60-us dependent chain per alignment on the path otherwise.
-    const bool overlap = !nt && !P->exchange && !std::getenv("PGX_NO_OVERLAP");
+    // (Record-sharded mode too: the exchange buffers have one slot per window in flight, and every process enqueues its
+    // collectives in the same order because the host logic is the same function of replicated results.)
+    const bool overlap = !nt && !std::getenv("PGX_NO_OVERLAP");
     if (overlap) {
         PGX_HIP(d_counters2.alloc(C_COUNT * 4));
         PGX_HIP(hipMemsetAsync(d_counters2.p, 0, C_COUNT * 4, st));
-        PGX_HIP(d_best2.alloc((size_t)window_cap * 8));
+        if (!P->exchange) PGX_HIP(d_best2.alloc((size_t)window_cap * 8));
         PGX_HIP(d_flags2.alloc(4 * (size_t)window_cap));
         PGX_HIP(d_pairsW2.alloc((size_t)pair_cap * sizeof(Pair)));
         if (need_gscratch) PGX_HIP(d_gscratch2.alloc((size_t)diag_grid * gs_stride * 4));
@@ -2398,8 +2447,13 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     const uint32_t shard_count = P->shard_count > 0 ? (uint32_t)P->shard_count : 1u;
     const uint32_t shard_index = P->shard_count > 0 ? (uint32_t)P->shard_index : 0u;
     const bool count_replicated = shard_index == 0;  // work every process repeats is counted by the first one only
+    // test hook (tests/test_gpu_cluster_sharded.py): PGX_INJECT_ERROR="<rank>:<n>" makes that process report a pair
+    // buffer overflow with its n-th exchange, to check that every process then leaves at the same point
+    int inject_rank = -1;
+    uint64_t inject_at = 0, n_exchanges = 0;
+    if (const char *e = std::getenv("PGX_INJECT_ERROR")) { unsigned long long at = 0; if (sscanf(e, "%d:%llu", &inject_rank, &at) == 2) inject_at = at; else inject_rank = -1; }
     uint64_t visits_rc = 0;
-    unsigned long long *const d_best_set[2] = {d_best, d_best2.as<unsigned long long>()};
+    unsigned long long *const d_best_set[2] = {d_best, P->exchange ? d_best + PGX_EXCHANGE_WORDS : d_best2.as<unsigned long long>()};
     uint8_t *const d_flags_set[2] = {d_flags.as<uint8_t>(), d_flags2.as<uint8_t>()};
     std::vector<uint8_t> status(window_cap);
     HostVec<uint8_t> strand_of(ctx, 11, n, (uint8_t)0);
@@ -2420,6 +2474,13 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             ++gpu_aligned;
             gpu_aligned_bytes += h_len[pp[i].q] + h_len[pp[i].r];
         }
+    };
+    auto window_error = [&](uint32_t e, uint32_t at) {   // (the word is the OR over all processes in the record-sharded mode)
+        pgx_set_error("pgx_cluster_greedy: capacity failure in the window at %u%s:%s%s%s%s%s", at,
+                      P->exchange ? " (on this or another process)" : "",
+                      e & E_TOUCHED ? " append scratch list full;" : "", e & E_POOL ? " overflow pool of the word index full;" : "",
+                      e & E_TABLE ? " exact table of the filter overflowed;" : "",
+                      e & E_BAND ? " alignment band wider than 64 diagonals;" : "", e & E_PAIRS ? " candidate pair buffer overflow;" : "");
     };
     const bool trace = std::getenv("PGX_TRACE") != nullptr;
     const uint32_t filter_grid = 4096u;
@@ -2529,7 +2590,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 ProfScope prof(ctx, "diag_kernel", st);
                 auto kern = h_len[b0] <= kDiagLdsSmall ? diag_kernel<kDiagLdsSmall> : diag_kernel<kDiagLdsCap>;
                 kern<<<dg, 64, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
-                                        P->band_width, P->identity, d_gs, gs_stride, dc + C_WIDE);
+                                        P->band_width, P->identity, d_gs, gs_stride, dc + C_WIDE, dc + C_ERR);
             }
             LAUNCH_CHECK();
             {
@@ -2546,18 +2607,22 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // enqueued on the stream by the caller's collective library; no host synchronisation)
         auto exchange_best = [&]() -> int {
             if (!P->exchange) return PGX_OK;
-            if (P->exchange(P->exchange_user, (void *)st) != 0) {
+            ++n_exchanges;
+            exchange_prepare_kernel<<<1, 1, 0, st>>>(dc, pair_cap, d_best,
+                                                     inject_rank == (int)shard_index && inject_at == n_exchanges ? (uint32_t)E_PAIRS : 0u);
+            if (P->exchange(P->exchange_user, (void *)st, set) != 0) {
                 pgx_set_error("pgx_cluster_greedy: the exchange callback failed in the window at %u", b0);
                 return PGX_ERR_INTERNAL;
             }
-            min_rows_kernel<<<(nb + 255) / 256, 256, 0, st>>>(static_cast<const unsigned long long *>(P->exchange_recv),
-                                                              shard_count, PGX_EXCHANGE_KEYS, nb, d_best);
+            min_rows_kernel<<<(nb + 255) / 256, 256, 0, st>>>(
+                static_cast<const unsigned long long *>(P->exchange_recv) + (size_t)set * shard_count * PGX_EXCHANGE_WORDS,
+                shard_count, PGX_EXCHANGE_WORDS, nb, d_best, dc + C_ERR);
             LAUNCH_CHECK();
             return PGX_OK;
         };
         // the window's pairs found since the last round_begin: evaluated, winners folded into best[]
         auto evaluate_round = [&]() -> int {
-            const PairSel sel{dc + C_EVAL0, dc + C_NW, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0};
+            const PairSel sel{dc + C_EVAL0, dc + C_NW, pair_cap, nullptr, 0, nullptr, nullptr, nullptr, b0, 0, 0};
             int rc = evaluate(pairsW, sel, d_best, 0);
             if (rc) return rc;
             return exchange_best();
@@ -2577,11 +2642,11 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // append list[*lo, *hi) to the index as round `epoch_idx` (the bit map of touched codes is the round's)
         auto index_append = [&](const uint32_t *list, const uint32_t *d_lo, const uint32_t *d_hi) -> int {
             ++epoch_idx;
-            zero_kernel<<<64, 256, 0, st>>>(d_newbits.as<uint4>(), ((size_t)n_codes / 32 + 2 + 3) / 4);
+            zero_kernel<<<128, 256, 0, st>>>(d_newbits.as<uint4>(), (size_t)bm_words / 4);
             ProfScope prof(ctx, "index_append", st);
             index_append_kernel<<<512, 256, 0, st>>>(DS, list, d_lo, d_hi, d_lines.as<IndexLine>(), epoch_idx,
-                                                     d_newbits.as<uint32_t>(), d_touched.as<Deferred>(), dc + C_TOUCH,
-                                                     (uint32_t)max_window_words, dc + C_ERR);
+                                                     d_newbits.as<uint32_t>(), b0, nb, d_touched.as<Deferred>(),
+                                                     dc + C_TOUCH, (uint32_t)max_window_words, dc + C_ERR);
             index_grow_kernel<<<256, 256, 0, st>>>(d_lines.as<IndexLine>(), d_poolp, d_idx.as<uint32_t>(),
                                                    (uint32_t)pool_cap, d_touched.as<Deferred>(), dc + C_TOUCH,
                                                    (uint32_t)max_window_words, dc + C_ERR);
@@ -2670,10 +2735,10 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             // pairs against those follow. Whatever the in-order walk on the host still needs
             // afterwards goes through follow-up rounds.
             {
-                const PairSel selK{nullptr, dc + C_NK, pair_cap_k, nullptr, 0, nullptr, d_hascand, d_accepted, b0, 0};
+                const PairSel selK{nullptr, dc + C_NK, pair_cap_k, nullptr, 0, nullptr, d_hascand, d_accepted, b0, 0, 2048};   // (a small block: all its pairs at once, the second round then finds nothing left)
                 int rc = evaluate(d_pairsK.as<Pair>(), selK, nullptr, 0);
                 if (rc) return rc;
-                const PairSel selK2{nullptr, dc + C_NK, pair_cap_k, nullptr, 0, d_hascand, d_accepted, nullptr, b0, 1};
+                const PairSel selK2{nullptr, dc + C_NK, pair_cap_k, nullptr, 0, d_hascand, d_accepted, nullptr, b0, 1, 0};
                 rc = evaluate(d_pairsK.as<Pair>(), selK2, nullptr, 0);
                 if (rc) return rc;
             }
@@ -2695,11 +2760,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 int rc = begin_host_side(); if (rc) return rc;
             }
             PGX_HIP(spin_sync(st));
-            if (h_cnt.p[C_ERR]) {
-                pgx_set_error("pgx_cluster_greedy: word index failure %u in the window at %u (1 = touched list, 2 = overflow "
-                              "pool, 3 = exact table)", h_cnt.p[C_ERR], b0);
-                return PGX_ERR_CAPACITY;
-            }
+            if (h_cnt.p[C_ERR]) { window_error(h_cnt.p[C_ERR], b0); return PGX_ERR_CAPACITY; }
             if (first_block) {
                 n_listed = h_cnt.p[C_NEW];
                 for (uint32_t i = 0; i < n_listed; ++i) status[h_new.p[i] - b0] = ST_REP;
@@ -2793,7 +2854,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 std::copy(flight.begin(), flight.end(), h_list.p);
                 PGX_HIP(hipMemcpyAsync(d_list.p, h_list.p, (size_t)nl * 4, hipMemcpyHostToDevice, st));
                 {
-                    const PairSel selL{nullptr, nullptr, 0, d_list.as<uint32_t>(), nl, nullptr, nullptr, nullptr, b0, 0};
+                    const PairSel selL{nullptr, nullptr, 0, d_list.as<uint32_t>(), nl, nullptr, nullptr, nullptr, b0, 0, 0};
                     int rc = evaluate(d_pairsK.as<Pair>(), selL, nullptr, nl);
                     if (rc) return rc;
                 }
@@ -2882,10 +2943,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 PGX_HIP(spin_sync(st));
             }
             nW = p_cnt->p[C_NW];
-            if (p_cnt->p[C_ERR]) {
-                pgx_set_error("pgx_cluster_greedy: word index failure %u in the window at %u", p_cnt->p[C_ERR], b0);
-                return PGX_ERR_CAPACITY;
-            }
+            if (p_cnt->p[C_ERR]) { window_error(p_cnt->p[C_ERR], b0); return PGX_ERR_CAPACITY; }
             if (nW > pair_cap) {
                 pgx_set_error("pgx_cluster_greedy: candidate pair buffer overflow (%u > %u) in the window at %u", nW, pair_cap, b0);
                 return PGX_ERR_CAPACITY;

@@ -84,14 +84,18 @@ def _cluster_worker(rank, world, port, out_dir):
     got, evaluated = sharded_model.run(seqs, p, oracle, pack, rank, world, cluster.group_all_gather(dist.group.WORLD),
                                        cluster.fold_best_keys, cluster.owner_of, window=16)
     # (2) the C-ABI callback as the library calls it: enqueue-only all-gather of the send buffer
-    send = torch.full((cluster.EXCHANGE_KEYS,), -1, dtype=torch.int64)
-    send[rank::world] = 1000 + rank                                   # this rank's members
-    send[7] = -(2 ** 63) + rank                                       # top bit set: unsigned order matters
-    recv = torch.zeros((world, cluster.EXCHANGE_KEYS), dtype=torch.int64)
+    send, recv = cluster.exchange_buffers(world, 'cpu')
+    assert tuple(send.shape) == (2, cluster.EXCHANGE_KEYS + 8)         # two windows in flight; keys + the error word
+    send[1].fill_(-1)
+    send[1, rank::world] = 1000 + rank                                # this rank's members (slot 1)
+    send[1, 7] = -(2 ** 63) + rank                                    # top bit set: unsigned order matters
+    send[1, cluster.EXCHANGE_KEYS] = 16 if rank == world - 1 else 0   # the last rank reports a failure
     sp, keep = cluster.shard_params(p, rank, world, send, recv, cluster.group_all_gather(dist.group.WORLD))
     assert (sp.shard_index, sp.shard_count) == (rank, world) and sp.identity == p.identity
-    assert sp.exchange(None, None) == 0
-    folded = cluster.fold_best_keys(recv.numpy())
+    assert sp.exchange(None, None, 1) == 0
+    assert not recv[0].any()                                          # the other slot is untouched
+    folded = cluster.fold_best_keys(recv[1].numpy()[:, :cluster.EXCHANGE_KEYS])
+    assert int(np.bitwise_or.reduce(recv[1].numpy()[:, cluster.EXCHANGE_KEYS])) == 16   # every rank sees the failure
 
     # (3) the fold of the per-rank partial outputs
     def host_reduce(op):

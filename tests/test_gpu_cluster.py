@@ -389,8 +389,7 @@ def test_errors_are_reported_and_leave_the_context_usable(gpu_ctx):
     import torch
     from pangenomix_amd import cluster
     res, off, _ = synth.ProteinSet(30, 500, 800, 150, 77).nr_arrays()
-    send = torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device='cuda:0')
-    recv = torch.empty((1, cluster.EXCHANGE_KEYS), dtype=torch.int64, device='cuda:0')
+    send, recv = cluster.exchange_buffers(1, 'cuda:0')
     calls = []
 
     def failing(r, s_, stream):

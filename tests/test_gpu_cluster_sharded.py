@@ -17,20 +17,21 @@ from test_gpu_cluster import assert_same, assert_same_nt, nt_params
 pytestmark = pytest.mark.gpu
 
 
-def run_virtual_ranks(res, off, p, world):
+def run_virtual_ranks(res, off, p, world, expect_errors=False):
     import torch
     torch.cuda.init()
     dev = torch.device('cuda', 0)
-    sends = [torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device=dev) for _ in range(world)]
-    recvs = [torch.empty((world, cluster.EXCHANGE_KEYS), dtype=torch.int64, device=dev) for _ in range(world)]
+    bufs = [cluster.exchange_buffers(world, dev) for _ in range(world)]
+    sends, recvs = [b[0] for b in bufs], [b[1] for b in bufs]
     barrier = threading.Barrier(world)
     results, errors = [None] * world, []
 
-    def all_gather(recv, send, stream):
+    def all_gather(recv, send, stream):             # (recv / send: one slot of this rank's buffers)
+        slot = next(s_ for s_ in range(cluster.EXCHANGE_SLOTS) if any(send.data_ptr() == b[s_].data_ptr() for b in sends))
         torch.cuda.synchronize()                    # this rank's keys are complete
         barrier.wait()
         for r in range(world):
-            recv[r].copy_(sends[r])
+            recv[r].copy_(sends[r][slot])
         torch.cuda.synchronize()
         barrier.wait()                              # every rank has read all contributions
 
@@ -51,6 +52,8 @@ def run_virtual_ranks(res, off, p, world):
         t.start()
     for t in threads:
         t.join()
+    if expect_errors:
+        return errors
     assert not errors, errors
     return results
 
@@ -116,8 +119,7 @@ def test_single_rank_group_is_the_plain_path(gpu_ctx):
     import torch
     res, off, _ = synth.protein_set('small').nr_arrays()
     p = params()
-    send = torch.empty(cluster.EXCHANGE_KEYS, dtype=torch.int64, device='cuda:0')
-    recv = torch.empty((1, cluster.EXCHANGE_KEYS), dtype=torch.int64, device='cuda:0')
+    send, recv = cluster.exchange_buffers(1, 'cuda:0')
     calls = []
 
     def all_gather(r, s_, stream):
@@ -159,3 +161,43 @@ def test_randomized_sets_on_virtual_ranks_match_oracle(seed):
     results = run_virtual_ranks(res, off, p, 2 + seed % 2)
     assert_replicated(results)
     (assert_same_nt if nucleotide else assert_same)(fold(results), oracle.cluster_greedy(res, off, p))
+
+
+@pytest.mark.slow
+def test_cfg4_on_two_virtual_ranks_matches_single_process(gpu_ctx):
+    """BASELINE config 4 (4000 synthetic genomes, 7.3 M non-redundant proteins) record-sharded over 2 virtual ranks,
+    windows overlapping on two streams with their own exchange slots: clusters, members, identities and every
+    counter equal the single-process result, which test_cfg4_shape_properties_and_prefix_parity ties to the
+    size-independent properties and to the oracle on a prefix."""
+    res, off, _ = synth.protein_set('cfg-4').nr_arrays()
+    p = params()
+    whole = gpu_ctx.cluster_greedy(res, off, p)
+    results = run_virtual_ranks(res, off, p, 2)
+    assert_replicated(results)
+    assert_same(fold(results), whole)
+
+
+def test_one_ranks_capacity_failure_ends_every_rank(monkeypatch):
+    """A capacity failure on ONE process (here injected: rank 1 reports a pair buffer overflow with its 3rd exchange)
+    travels with the exchanged keys: every rank returns the error from the same point of the window loop, none is
+    left waiting in a collective (this test would hang otherwise)."""
+    monkeypatch.setenv('PGX_WINDOW', '2048')
+    monkeypatch.setenv('PGX_INJECT_ERROR', '1:3')
+    ps = synth.ProteinSet(30, 500, 800, 150, 77)
+    res, off, _ = ps.nr_arrays()
+    errors = run_virtual_ranks(res, off, params(), 2, expect_errors=True)
+    assert sorted(r for r, _ in errors) == [0, 1]
+    assert all('candidate pair buffer overflow' in str(e) for _, e in errors), errors
+
+
+def test_overlapped_windows_under_exchange_match_the_serial_loop(monkeypatch):
+    """Two windows in flight with the exchange callback (slots 0 and 1 both used) against PGX_NO_OVERLAP=1."""
+    monkeypatch.setenv('PGX_WINDOW', '1024')
+    ps = synth.ProteinSet(30, 500, 800, 150, 77)
+    res, off, _ = ps.nr_arrays()
+    p = params()
+    both = run_virtual_ranks(res, off, p, 2)
+    monkeypatch.setenv('PGX_NO_OVERLAP', '1')
+    serial = run_virtual_ranks(res, off, p, 2)
+    assert_same(fold(both), fold(serial))
+    assert_same(fold(both), oracle.cluster_greedy(res, off, p))
