@@ -314,6 +314,16 @@ int pgx_pan_core_coo_rng(pgx_ctx *ctx, const int32_t *rows, const int32_t *genom
                          uint32_t n_genes, uint32_t n_genomes, uint32_t *mt_key, int32_t *mt_pos, uint32_t n_iter,
                          int32_t *out_perms, int32_t *out_pan, int32_t *out_core, uint64_t *out_duplicates);
 
+/* The whole of estimate_pan_core_size() (pangenome_analysis.py:51-98) from the gene x genome table's COO arrays:
+ * `values` (the table's stored values, int64; may be NULL) are checked to be all 1 (out_not_one = how many are
+ * not; the curves are then NOT computed), the permutations are drawn from the generator state, and the result is
+ * written as the reference returns it: out_table float64 [n_iter][2 * n_genomes], pan curves in columns
+ * 0..n_genomes-1, core curves behind them. out_perms [n_iter][n_genomes] receives the permutations used. */
+int pgx_pan_core_table(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, const int64_t *values,
+                       uint64_t n_records, uint32_t n_genes, uint32_t n_genomes, uint32_t *mt_key, int32_t *mt_pos,
+                       uint32_t n_iter, int32_t *out_perms, double *out_table, uint64_t *out_duplicates,
+                       uint64_t *out_not_one);
+
 /* feature names (pangenome.py:1944-1969) as fixed-width zero-padded ASCII records (numpy 'S<width>'):
  * <prefix><cluster>[<variant><member>]; variant NULL = gene names */
 int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,

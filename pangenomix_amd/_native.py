@@ -82,6 +82,8 @@ SIGNATURES = {
     'pgx_legacy_shuffles': (C.c_int, [_P, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, _P]),
     'pgx_pan_core_coo_rng': (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_int32), C.c_uint32,
                                       _P, _P, _P, C.POINTER(C.c_uint64)]),
+    'pgx_pan_core_table': (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_int32), C.c_uint32,
+                                    _P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     'pgx_format_labels': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_format_labels_ucs4': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_fasta_write_clustered': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _S, _S, _S, _S, _S]),
@@ -307,6 +309,26 @@ class Context(object):
                                          _ptr(mt_key), C.byref(pos), int(n_iter), _ptr(perms), _ptr(pan), _ptr(core),
                                          C.byref(dup)))
         return pan, core, int(dup.value), perms, int(pos.value)
+
+    def pan_core_table(self, rows, genomes, values, n_genes, n_genomes, n_iter, mt_key, mt_pos):
+        """(table float64 [n_iter, 2 n_genomes], duplicates, values that are not 1, perms, new_pos): the whole of
+        estimate_pan_core_size() in one library call (pgx.h: pgx_pan_core_table). `values`: the table's stored
+        values as int64, or None."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        genomes = np.ascontiguousarray(genomes, dtype=np.int32)
+        if rows.shape != genomes.shape or rows.ndim != 1:
+            raise ValueError('rows and genomes must be 1-D arrays of equal length')
+        if values is not None:
+            values = np.ascontiguousarray(values, dtype=np.int64)
+            if values.shape != rows.shape:
+                raise ValueError('values must match the coordinates')
+        perms = np.empty((int(n_iter), int(n_genomes)), dtype=np.int32)
+        table = np.empty((int(n_iter), 2 * int(n_genomes)), dtype=np.float64)
+        dup, bad, pos = C.c_uint64(0), C.c_uint64(0), C.c_int32(int(mt_pos))
+        check(lib().pgx_pan_core_table(self._h, _ptr(rows), _ptr(genomes), _ptr(values), rows.size, int(n_genes),
+                                       int(n_genomes), _ptr(mt_key), C.byref(pos), int(n_iter), _ptr(perms), _ptr(table),
+                                       C.byref(dup), C.byref(bad)))
+        return table, int(dup.value), int(bad.value), perms, int(pos.value)
 
     def pan_core(self, bits, n_genes, perms):
         perms = np.ascontiguousarray(perms, dtype=np.int32)

@@ -2673,6 +2673,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // index, and the pass against them assigns most of the remaining members; a second round confirms
         // the members the first round's representatives rejected (the outliers of their families). All on
         // the device: the host learns the outcome with the first block's results.
+        uint32_t n_listed = 0;
         if (sweep) { int rc = begin_host_side(); if (rc) return rc; }
         if (!sweep) {   // ---- discovery rounds and blocks (a sweep window has neither: nothing is appended) ----
         if (overlap && S.sweeps > 1)   // from here on the index is written: the window before must have closed
@@ -2707,7 +2708,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // representative are struck out again, and every other window member is compared with what is
         // left: the block's new representatives. Pair work stays close to what the one-by-one pass does.
         bool first_block = true;
-        uint32_t n_listed = 0;     // discovery representatives the host has seen
+        n_listed = 0;              // discovery representatives the host has seen
         uint32_t n_struck = 0;     // members struck out of the index so far (offsets into the pinned list)
         for (;;) {
             select_block_kernel<<<1, kSelThreads, 0, st>>>(d_best, d_done, d_inblk, b0, nb, block_cap,
@@ -3035,9 +3036,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         }
         t_close += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_c0).count();
         if (trace2)
-            fprintf(stderr, "[pgx] window %4llu b0 %8u len %5u..%5u blocks %2llu reps +%5zu (total %7zu) pairs %7u  %.2f ms\n",
-                    (unsigned long long)S.sweeps, b0, h_len[b0], h_len[b0 + nb - 1],
-                    (unsigned long long)(n_blocks - blocks_before), rep_seq.size() - n_reps, rep_seq.size(), nW,
+            fprintf(stderr, "[pgx] window %4llu b0 %8u nb %6u len %5u..%5u blocks %2llu reps +%5zu (discovery %5u) (total %7zu) pairs %7u  %.2f ms\n",
+                    (unsigned long long)S.sweeps, b0, nb, h_len[b0], h_len[b0 + nb - 1],
+                    (unsigned long long)(n_blocks - blocks_before), rep_seq.size() - n_reps, n_listed, rep_seq.size(), nW,
                     1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_sweep0).count());
         if (!sweep) { cursor += nb; continue; }
         sweep_at += nb;
@@ -3103,7 +3104,7 @@ extern "C" int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const u
     PGX_HIP(d_res.alloc(total_in + 16));
     PGX_HIP(d_off.alloc(((size_t)n_in + 1) * 8));
     if (n_in) {
-        PGX_HIP(hipMemcpyAsync(d_res.p, residues, total_in, hipMemcpyHostToDevice, ctx->stream));
+        { int rc = pgx_staged_h2d(ctx, d_res.p, residues, total_in, ctx->stream); if (rc) return rc; }   // (pageable: staged by a few threads)
         PGX_HIP(hipMemcpyAsync(d_off.p, offsets, ((size_t)n_in + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     return pgx_cluster_greedy_dev(ctx, d_res.as<uint8_t>(), d_off.as<uint64_t>(), n_in, total_in, P, out_cluster,

@@ -674,53 +674,112 @@ static int pgx_fasta_write_clustered_impl(const pgx_fasta_set *S, const int32_t 
 // that is a no-op when the draw is rejected (x[i] <-> x[i]), and the position only advances on acceptance -- no
 // unpredictable branch per draw (the rejection loop mispredicts on a third of the draws). The generator's 624
 // outputs of a block are tempered in one vectorisable pass.
-static void mt_block(uint32_t *mt, uint32_t *out) {
-    auto twist = [&](int k, int k1, int km) {
-        const uint32_t y = (mt[k] & 0x80000000u) | (mt[k1] & 0x7fffffffu);
-        mt[k] = mt[km] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
-    };
-    for (int k = 0; k < 227; ++k) twist(k, k + 1, k + 397);
-    for (int k = 227; k < 623; ++k) twist(k, k + 1, k - 227);
-    twist(623, 0, 396);
+static void mt_block(uint32_t *__restrict__ mt, uint32_t *__restrict__ out) {
+    // (plain counted loops over disjoint ranges, written so that the compiler vectorises them: an element depends on
+    // elements 1 and 397 places ahead or 227 behind, never on a neighbour computed in the same vector step)
+    constexpr uint32_t kUp = 0x80000000u, kLo = 0x7fffffffu, kA = 0x9908b0dfu;
+    for (int k = 0; k < 227; ++k) {
+        const uint32_t y = (mt[k] & kUp) | (mt[k + 1] & kLo);
+        mt[k] = mt[k + 397] ^ (y >> 1) ^ ((0u - (y & 1u)) & kA);
+    }
+    for (int k = 227; k < 454; ++k) {          // (two stretches of 227 and 169: each reads what the stretch before wrote)
+        const uint32_t y = (mt[k] & kUp) | (mt[k + 1] & kLo);
+        mt[k] = mt[k - 227] ^ (y >> 1) ^ ((0u - (y & 1u)) & kA);
+    }
+    for (int k = 454; k < 623; ++k) {
+        const uint32_t y = (mt[k] & kUp) | (mt[k + 1] & kLo);
+        mt[k] = mt[k - 227] ^ (y >> 1) ^ ((0u - (y & 1u)) & kA);
+    }
+    {
+        const uint32_t y = (mt[623] & kUp) | (mt[0] & kLo);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((0u - (y & 1u)) & kA);
+    }
     for (int k = 0; k < 624; ++k) {
         uint32_t y = mt[k];
         y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
         out[k] = y;
     }
 }
-int pgx_legacy_shuffles(uint32_t *key, int32_t *pos, uint32_t n, uint32_t n_iter, int32_t *out_perms) {
+// Two phases, because the position of an iteration's first draw depends on every rejection before it but the
+// PERMUTATIONS do not depend on each other: (1) one serial walk over the stream that only counts -- per draw a mask,
+// a compare and a decrement, no memory traffic beyond the draws themselves -- and notes where each iteration starts;
+// (2) the Fisher-Yates swaps of the iterations, each from its own start, on all cores. [One serial loop doing both:
+// 3.0 ms per 1000 x 400 on the benchmark host, the critical path of estimate_pan_core_size() beside the upload.]
+static int pgx_legacy_shuffles_impl(uint32_t *key, int32_t *pos, uint32_t n, uint32_t n_iter, int32_t *out_perms) {
     if (!key || !pos || (n && n_iter && !out_perms) || *pos < 0 || *pos > 624) {
         pgx_set_error("pgx_legacy_shuffles: invalid argument");
         return PGX_ERR_INVALID;
     }
-    uint32_t buf[624];
-    int32_t p = *pos;
-    for (int k = p; k < 624; ++k) {     // what is left of the current block
+    if (n < 2 || n_iter == 0) {      // nothing is drawn
+        for (uint32_t it = 0; it < n_iter; ++it) for (uint32_t i = 0; i < n; ++i) out_perms[(size_t)it * n + i] = (int32_t)i;
+        return PGX_OK;
+    }
+    // The stream of tempered outputs from the current position on, generated block by block as the count needs them.
+    // Never re-allocated while the workers read it: room for four draws per position (every draw is accepted with
+    // probability > 1/2, so a seeded generator cannot come near that; running into it is reported, not survived).
+    const bool trace_ = std::getenv("PGX_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap_ = [&](const char *what) { if (trace_) fprintf(stderr, "[pgx] shuffles: %-18s at %7.3f ms\n", what, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count()); };
+    const size_t cap = 4 * (size_t)n_iter * n + 2 * 624;
+    std::unique_ptr<uint32_t[]> raw_mem(new uint32_t[cap]);
+    uint32_t *raw = raw_mem.get();
+    size_t raw_n = 624 - (size_t)*pos;
+    for (int k = *pos; k < 624; ++k) {     // what is left of the current block
         uint32_t y = key[k];
         y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
-        buf[k] = y;
+        raw[(size_t)(k - *pos)] = y;
     }
-    for (uint32_t it = 0; it < n_iter; ++it) {
-        int32_t *x = out_perms + (size_t)it * n;
-        for (uint32_t i = 0; i < n; ++i) x[i] = (int32_t)i;
-        uint32_t i = n ? n - 1 : 0;
+    size_t last_block_at = 0;              // where the block generated last starts in `raw`
+    bool fresh = false;                    // a new block has been generated
+    std::vector<uint64_t> start((size_t)n_iter + 1, 0);
+    bool overflow = false;
+    size_t cur = 0;
+    for (uint32_t it = 0; it < n_iter && !overflow; ++it) {
+        start[it] = cur;
+        uint32_t i = n - 1;
         while (i >= 1) {
-            if (p >= 624) { mt_block(key, buf); p = 0; }
-            const int32_t stop = 624;
-            int32_t k = p;
-            for (; k < stop && i >= 1; ++k) {
-                const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(i);     // smallest bit mask >= i
-                const uint32_t j = buf[k] & mask;
+            if (cur == raw_n) {
+                if (raw_n + 624 > cap) { overflow = true; break; }
+                mt_block(key, raw + raw_n);
+                last_block_at = raw_n; fresh = true;
+                raw_n += 624;
+            }
+            // draws of the stretch where the mask (smallest 2^k - 1 >= i) stays the same: i down to the next power of two
+            const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(i);
+            const uint32_t floor_i = mask >> 1;
+            size_t k = cur;
+            for (; k < raw_n && i > floor_i; ++k) i -= (raw[k] & mask) <= i;
+            cur = k;
+        }
+    }
+    if (overflow) { pgx_set_error("pgx_legacy_shuffles: generator stream longer than four draws per position"); return PGX_ERR_INTERNAL; }
+    lap_("count done");
+    // (2) the swaps, iterations spread over a few cores (helpers that SPIN beside the count, waiting for batches, cost
+    // more than they gain on hosts with a CPU quota)
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int threads = (size_t)n_iter * n < (1u << 16) ? 1 : (int)std::min(8u, hw);
+    constexpr size_t kBatch = 8;
+    parallel_for(((size_t)n_iter + kBatch - 1) / kBatch, threads, [&](size_t w) {
+        for (size_t it = w * kBatch; it < std::min<size_t>(n_iter, (w + 1) * kBatch); ++it) {
+            int32_t *x = out_perms + it * n;
+            for (uint32_t i = 0; i < n; ++i) x[i] = (int32_t)i;
+            uint32_t i = n - 1;
+            for (size_t k = start[it]; i >= 1; ++k) {   // a rejected draw swaps a position with itself: no branch per draw
+                const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(i);
+                const uint32_t j = raw[k] & mask;
                 const uint32_t acc = j <= i;
                 const uint32_t jj = acc ? j : i;
                 const int32_t t = x[i]; x[i] = x[jj]; x[jj] = t;
                 i -= acc;
             }
-            p = k;
         }
-    }
-    *pos = p;
+    });
+    lap_("swaps done");
+    *pos = fresh ? (int32_t)(cur - last_block_at) : (int32_t)(*pos + (int32_t)cur);
     return PGX_OK;
+}
+int pgx_legacy_shuffles(uint32_t *key, int32_t *pos, uint32_t n, uint32_t n_iter, int32_t *out_perms) {
+    return guarded("pgx_legacy_shuffles", [&] { return pgx_legacy_shuffles_impl(key, pos, n, n_iter, out_perms); });
 }
 
 // Feature names as fixed-width, zero-padded ASCII records (numpy dtype 'S<width>'):

@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "pgx_internal.h"
 
@@ -187,6 +188,26 @@ __global__ __launch_bounds__(256) void pan_core_reduce_kernel(const uint32_t *__
     }
 }
 
+// The same sum written as the table estimate_pan_core_size() returns: float64 [n_iter][2 S], pan curves in columns
+// 0..S-1, core curves in S..2S-1 (pangenome_analysis.py:93-97) -- the int -> float conversion and the side-by-side
+// layout cost the host 1-2 ms per call (np.hstack + astype) and nothing here.
+__global__ __launch_bounds__(256) void pan_core_reduce_table_kernel(const uint32_t *__restrict__ partial,
+                                                                   uint32_t n_partials, uint32_t n_iter, uint32_t S,
+                                                                   double *__restrict__ table) {
+    const size_t n_out = (size_t)n_iter * S;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_out; e += (size_t)gridDim.x * blockDim.x) {
+        uint32_t pan = 0, core = 0;
+        for (uint32_t p = 0; p < n_partials; ++p) {
+            const uint32_t x = partial[(size_t)p * n_out + e];
+            pan += x & 0xFFFFu;
+            core += x >> 16;
+        }
+        const size_t it = e / S, j = e - it * S;
+        table[it * 2 * S + j] = (double)pan;
+        table[it * 2 * S + S + j] = (double)core;
+    }
+}
+
 // counters[0] += records whose bit was already set (duplicate coordinates), counters[1] += records
 // with a row or genome index out of range (never written). atomicOr returns the word before the
 // update, so a set bit there is a duplicate: the check the reference-side table needs (a 0/1 matrix
@@ -231,7 +252,7 @@ __global__ __launch_bounds__(256) void row_counts_kernel(const unsigned long lon
 
 // K3 device buffers of the host-pointer entry points live in the context's grow-only workspace
 // (slots after the clustering's), so repeated calls neither allocate nor free.
-enum { PC_SLOT_ROWS = 80, PC_SLOT_GENOMES, PC_SLOT_BITS, PC_SLOT_PERMS, PC_SLOT_PAN, PC_SLOT_CORE, PC_SLOT_WS, PC_SLOT_CNT, PC_SLOT_COUNTS };
+enum { PC_SLOT_ROWS = 80, PC_SLOT_GENOMES, PC_SLOT_BITS, PC_SLOT_PERMS, PC_SLOT_PAN, PC_SLOT_CORE, PC_SLOT_WS, PC_SLOT_CNT, PC_SLOT_COUNTS, PC_SLOT_TABLE };
 struct PcBuf : DevBuf {
     PcBuf(pgx_ctx *c, int s) { ctx = c; slot = s; }
 };
@@ -284,8 +305,9 @@ static int upload_and_build_bitmap(pgx_ctx *ctx, const int32_t *rows, const int3
     PGX_HIP(d_bits.alloc(nbits));
     PGX_HIP(d_cnt.alloc(16));
     if (n_records) {
-        PGX_HIP(hipMemcpyAsync(d_rows.p, rows, n_records * 4, hipMemcpyHostToDevice, ctx->stream));
-        PGX_HIP(hipMemcpyAsync(d_genomes.p, genomes, n_records * 4, hipMemcpyHostToDevice, ctx->stream));
+        int rc = pgx_staged_h2d(ctx, d_rows.p, rows, n_records * 4, ctx->stream);
+        if (rc == PGX_OK) rc = pgx_staged_h2d(ctx, d_genomes.p, genomes, n_records * 4, ctx->stream);
+        if (rc != PGX_OK) return rc;
     }
     return pgx_presence_bitmap_dev(ctx, d_rows.as<int32_t>(), d_genomes.as<int32_t>(), n_records, n_rows,
                                    n_genomes, d_bits.as<uint64_t>(), d_cnt.as<uint64_t>(), ctx->stream);
@@ -426,6 +448,83 @@ int pgx_pan_core_coo_rng(pgx_ctx *ctx, const int32_t *rows, const int32_t *genom
     if (n_iter && n_genomes) {
         rc = pan_core_from_device_bitmap(ctx, d_bits.as<uint64_t>(), n_genes, n_genomes, out_perms, n_iter, out_pan, out_core);
         if (rc != PGX_OK) return rc;
+    }
+    uint64_t cnt[2] = {0, 0};
+    PGX_HIP(hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipStreamSynchronize(ctx->stream));
+    PGX_REQUIRE(cnt[1] == 0, "record with row or genome index out of range");
+    if (out_duplicates) *out_duplicates = cnt[0];
+    return PGX_OK;
+}
+
+// estimate_pan_core_size() from the table's COO arrays to the float64 result in ONE call (pangenome_analysis.py:51-98):
+// on host threads, side by side -- the legacy-generator draws, the check that every stored value is 1, the staged
+// upload of the coordinates; on the device -- bitmap, curves, the [n_iter][2 S] float64 table; one copy down.
+int pgx_pan_core_table(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes, const int64_t *values,
+                       uint64_t n_records, uint32_t n_genes, uint32_t n_genomes, uint32_t *mt_key, int32_t *mt_pos,
+                       uint32_t n_iter, int32_t *out_perms, double *out_table, uint64_t *out_duplicates,
+                       uint64_t *out_not_one) {
+    PGX_REQUIRE(ctx, "NULL context");
+    PGX_REQUIRE(n_records == 0 || (rows && genomes), "NULL record arrays");
+    PGX_REQUIRE(mt_key && mt_pos, "NULL generator state");
+    PGX_REQUIRE(n_iter == 0 || n_genomes == 0 || (out_perms && out_table), "NULL argument");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    int rc_draw = PGX_OK;
+    std::string draw_error;
+    std::thread draw([&]() {
+        rc_draw = pgx_legacy_shuffles(mt_key, mt_pos, n_genomes, n_iter, out_perms);
+        if (rc_draw != PGX_OK) draw_error = pgx_last_error();     // (the error text is thread-local)
+    });
+    // every stored value must be 1 (the OR/AND form equals the reference's loop only for a 0/1 table): checked here,
+    // on a few threads, instead of by a 3 ms numpy pass before the call
+    uint64_t not_one = 0;
+    std::vector<std::thread> checkers;
+    std::vector<uint64_t> bad(4, 0);
+    if (values && n_records) {
+        const unsigned T = n_records < (1u << 20) ? 1u : 4u;
+        for (unsigned t = 0; t < T; ++t)
+            checkers.emplace_back([&, t, T]() {
+                const uint64_t a = n_records * t / T, b = n_records * (t + 1) / T;
+                uint64_t c = 0;
+                for (uint64_t i = a; i < b; ++i) c += values[i] != 1;
+                bad[t] = c;
+            });
+    }
+    PcBuf d_bits(ctx, PC_SLOT_BITS), d_cnt(ctx, PC_SLOT_CNT);
+    int rc = upload_and_build_bitmap(ctx, rows, genomes, n_records, n_genes, n_genomes, d_bits, d_cnt);
+    draw.join();
+    for (auto &th : checkers) th.join();
+    for (uint64_t c : bad) not_one += c;
+    if (out_not_one) *out_not_one = not_one;
+    if (rc != PGX_OK) return rc;
+    if (rc_draw != PGX_OK) { pgx_set_error("%s", draw_error.c_str()); return rc_draw; }
+    if (n_iter && n_genomes && !not_one) {
+        const size_t nperm = (size_t)n_iter * n_genomes * 4;
+        const size_t nws = pgx_pan_core_workspace_bytes(n_genes, n_genomes, n_iter);
+        PcBuf d_perms(ctx, PC_SLOT_PERMS), d_ws(ctx, PC_SLOT_WS), d_table(ctx, PC_SLOT_TABLE);
+        PGX_HIP(d_perms.alloc(nperm));
+        PGX_HIP(d_ws.alloc(nws));
+        PGX_HIP(d_table.alloc(nperm * 4));
+        PGX_HIP(hipMemcpyAsync(d_perms.p, out_perms, nperm, hipMemcpyHostToDevice, ctx->stream));
+        const PanCoreGeom g = make_geom(n_genes);
+        {
+            const uint64_t items = (uint64_t)n_iter * g.wps;  // per stripe
+            const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * PC_STRIPES;
+            PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
+            ProfScope prof(ctx, "pan_core_sweep_kernel", ctx->stream);
+            pan_core_sweep_kernel<<<(uint32_t)blocks, PC_WAVES * 64, 0, ctx->stream>>>(
+                d_bits.as<uint4>(), g.stride * 8, d_perms.as<int32_t>(), n_iter, n_genomes, g.Ls, g.wps, g.Lw,
+                d_ws.as<uint32_t>());
+        }
+        PGX_HIP(hipGetLastError());
+        {
+            const size_t want = ((size_t)n_iter * n_genomes + 255) / 256;
+            ProfScope prof(ctx, "pan_core_reduce_kernel", ctx->stream);
+            pan_core_reduce_table_kernel<<<(uint32_t)(want < 2048 ? want : 2048), 256, 0, ctx->stream>>>(
+                d_ws.as<uint32_t>(), g.partials, n_iter, n_genomes, d_table.as<double>());
+        }
+        PGX_HIP(hipGetLastError());
+        PGX_HIP(hipMemcpyAsync(out_table, d_table.p, nperm * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     uint64_t cnt[2] = {0, 0};
     PGX_HIP(hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, ctx->stream));

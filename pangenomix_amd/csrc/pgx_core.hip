@@ -1,4 +1,7 @@
 // libpgx: context, error reporting, device info.
+#include <atomic>
+#include <thread>
+
 #include "pgx_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -54,6 +57,45 @@ static void prof_resolve(pgx_ctx *ctx) {
         }
         sl.pending.clear();
     }
+}
+
+int pgx_staged_h2d(pgx_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    constexpr size_t kChunk = 4u << 20;
+    constexpr int kStageSlot = 30;           // host scratch slot of the staging buffers
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = (unsigned)std::min<size_t>(std::min(4u, std::max(1u, hw / 2)), bytes / (2 * kChunk));
+    if (T < 2) { PGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return PGX_OK; }
+    HostVec<uint8_t> stage(ctx, kStageSlot, (size_t)T * 2 * kChunk);
+    if (!stage.ok() || !stage.data()) { PGX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return PGX_OK; }
+    while (ctx->stage_events.size() < 2 * (size_t)T) {
+        hipEvent_t e = nullptr;
+        PGX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->stage_events.push_back(e);
+    }
+    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    std::atomic<int> failed{0};
+    auto worker = [&](unsigned t) {
+        if (hipSetDevice(ctx->device_id) != hipSuccess) { failed = 1; return; }
+        unsigned k = 0;
+        for (size_t c = t; c < n_chunks && !failed.load(std::memory_order_relaxed); c += T, ++k) {
+            const unsigned b = 2 * t + (k & 1u);
+            uint8_t *buf = stage.data() + (size_t)b * kChunk;
+            // (the buffer's last DMA -- of this call or the one before -- must have read it; a never-recorded event is "done")
+            if (hipEventSynchronize(ctx->stage_events[b]) != hipSuccess) { failed = 1; return; }
+            const size_t at = c * kChunk, len = std::min(kChunk, bytes - at);
+            memcpy(buf, static_cast<const uint8_t *>(src) + at, len);
+            if (hipMemcpyAsync(static_cast<uint8_t *>(dst) + at, buf, len, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipEventRecord(ctx->stage_events[b], stream) != hipSuccess) { failed = 1; return; }
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(worker, t);
+    } catch (...) { failed = 1; }
+    if (!failed) worker(0);
+    for (auto &th : pool) th.join();
+    if (failed) { (void)hipGetLastError(); pgx_set_error("pgx_staged_h2d: a staged copy failed"); return PGX_ERR_HIP; }
+    return PGX_OK;
 }
 
 extern "C" {
@@ -149,6 +191,7 @@ void pgx_ctx_destroy(pgx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream2);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
     for (auto &a : ctx->arena)
         if (a.first) (void)hipFree(a.first);
     for (auto &a : ctx->host_arena)
