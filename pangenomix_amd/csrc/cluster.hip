@@ -65,7 +65,12 @@ constexpr int kDiscoveryRounds = 2;    // device-only discovery rounds before th
 constexpr uint32_t kBlockCap = 4096;   // most open members resolved together inside a window (512 for nucleotides)
 constexpr uint32_t kBlockCapMin = 64;  // what a block shrinks to when its candidate pairs overflow the buffer
 
-constexpr uint32_t kMaxLen = 32767;    // longest supported sequence
+constexpr uint32_t kMaxLen = 1u << 22;  // longest supported sequence (cd-hit's own limit is 655,360)
+// Up to this length a sequence takes the ordinary paths: its words fit the LDS sorter, and the diagonal histogram packs
+// hits and complexity-weighted hits of a diagonal into 16 bits each (hits <= query length; a nucleotide 4-mer weighs
+// up to 4, a protein 2-mer up to 2). Longer sequences -- a handful of giant proteins exist -- take a global-memory
+// word table and 64-bit histogram cells.
+constexpr uint32_t kPackedLenAa = 32767, kPackedLenNt = 16383;
 constexpr uint32_t kSentinel = 0xFFFFFFFFu;
 constexpr uint32_t kDiagLdsCap = 2048;  // diagonals / query 2-mers kept in LDS by the diag kernel
 constexpr uint32_t kDiagLdsSmall = 512; // ... for windows whose queries are that short (most of them)
@@ -81,7 +86,8 @@ enum : uint32_t { E_TOUCHED = 1,    // an append round set more entries aside th
                   E_POOL = 2,       // the overflow pool of the word index is full
                   E_TABLE = 4,      // the filter's exact table overflowed at the finest residue class
                   E_BAND = 8,       // a pair that passed the diagonal test has a band wider than kMaxBand
-                  E_PAIRS = 16 };   // the window's candidate pair buffer overflowed
+                  E_PAIRS = 16,     // the window's candidate pair buffer overflowed
+                  E_WORDMULT = 32 };// a word occurs more than 65535 times in one (giant, degenerate) sequence
 
 struct Pair {           // one (query, representative) candidate
     uint32_t q;         // sorted sequence index of the query
@@ -360,6 +366,62 @@ __global__ __launch_bounds__(THREADS) void words_hash_kernel(const uint8_t *__re
     if (tid == THREADS - 1) wcnt[k] = part[tid];
     for (uint32_t i = beg; i < beg + C; ++i)
         if (hk[i] != kSentinel) { wcode[o + idx] = hk[i]; wmult[o + idx] = (uint16_t)hc[i]; ++idx; }
+}
+
+// Sequences of more than 32768 words (rare: a handful of giant proteins): the same open-addressing table in a GLOBAL
+// scratch region of the workgroup (`slots` a power of two >= 2 x words, keys and counts), one workgroup per sequence.
+__global__ __launch_bounds__(1024) void words_huge_kernel(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
+                                                          const uint32_t *__restrict__ len, uint32_t k0, uint32_t k1,
+                                                          int word_len, int base, int nt, uint32_t *__restrict__ scratch,
+                                                          uint32_t slots, uint32_t *__restrict__ wcode,
+                                                          uint16_t *__restrict__ wmult, uint32_t *__restrict__ wcnt,
+                                                          uint32_t *__restrict__ err) {
+    __shared__ uint32_t part[1024];
+    const uint32_t k = k0 + blockIdx.x;
+    if (k >= k1) return;
+    const uint32_t tid = threadIdx.x;
+    uint32_t *hk = scratch + (size_t)blockIdx.x * 2u * slots, *hc = hk + slots;
+    const uint64_t o = off[k];
+    const uint8_t *s = res + o;
+    const uint32_t nw = len[k] - (uint32_t)word_len + 1u;
+    for (uint32_t i = tid; i < slots; i += 1024) { hk[i] = kSentinel; hc[i] = 0u; }
+    __threadfence();
+    __syncthreads();
+    for (uint32_t i = tid; i < nw; i += 1024) {
+        uint32_t key = 0;
+        bool bad = false;
+        for (int t = 0; t < word_len; ++t) { key = key * (uint32_t)base + s[i + t]; bad |= s[i + t] >= base; }
+        if (nt && bad) continue;
+        uint32_t slot = ((key * 0x9E3779B1u) >> 7) & (slots - 1u);
+        for (;;) {
+            const uint32_t was = atomicCAS(&hk[slot], kSentinel, key);
+            if (was == kSentinel || was == key) break;
+            slot = (slot + 1u) & (slots - 1u);
+        }
+        atomicAdd(&hc[slot], 1u);
+    }
+    __threadfence();
+    __syncthreads();
+    const uint32_t per = slots / 1024u, beg = tid * per;     // (slots >= 65536)
+    uint32_t mine = 0;
+    for (uint32_t i = beg; i < beg + per; ++i) mine += __builtin_nontemporal_load(&hk[i]) != kSentinel;
+    part[tid] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t idx = part[tid] - mine;
+    if (tid == 1023) wcnt[k] = part[tid];
+    for (uint32_t i = beg; i < beg + per; ++i) {
+        const uint32_t key = __builtin_nontemporal_load(&hk[i]);
+        if (key == kSentinel) continue;
+        const uint32_t c = __builtin_nontemporal_load(&hc[i]);
+        if (c > 65535u) atomicOr(err, (uint32_t)E_WORDMULT);   // (multiplicities are kept in 16 bits)
+        wcode[o + idx] = key; wmult[o + idx] = (uint16_t)c; ++idx;
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1255,8 +1317,10 @@ __device__ void band_from_histogram(DiagPtr d, int len1, int len2, int band_widt
     const int band_m = band_b + band_width - 1 < band_e ? band_b + band_width - 1 : band_e;
     const int w = band_m - band_b + 1;                         // diagonals in a window (<= 64; <= 0: none)
     const int T = band_e - band_m - 1 > 0 && w > 0 ? band_e - band_m - 1 : 0;   // windows after the first: starts band_b + 1 .. band_b + T
-    auto hits = [&](int i) { return (int)(d[i] & 0xFFFFu); };
-    auto weighted = [&](int i) { return (int)(d[i] >> 16); };
+    using Cell = std::remove_cv_t<std::remove_reference_t<decltype(d[0])>>;   // 16 + 16 bits, or 32 + 32 for giant queries
+    constexpr int kHalf = (int)sizeof(Cell) * 4;
+    auto hits = [&](int i) { return (int)(d[i] & ((Cell(1) << kHalf) - 1)); };
+    auto weighted = [&](int i) { return (int)(d[i] >> kHalf); };
     auto wave_max = [&](int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; };
     auto wave_min = [&](int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; };
     auto wave_sum = [&](int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; };
@@ -1348,16 +1412,20 @@ __device__ __forceinline__ int kd_code(const DevSeqs &S, const uint8_t *__restri
 // rep_seq == nullptr: p.r is already a sequence index (phase B)
 // CAP: diagonals / query 2-mers kept in LDS (larger pairs use the global scratch): 512 gives six waves per SIMD
 // where 2048 gives three -- a pair of 340-residue sequences at 0.8 identity needs 140 diagonals and 340 positions
-template <uint32_t CAP>
+// Cell: one diagonal's hits | complexity-weighted hits: 16 + 16 bits, or -- queries beyond kPackedLen*, always in the
+// global scratch -- 32 + 32.
+template <uint32_t CAP, typename Cell>
 __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__restrict__ rep_seq,
                                                  Pair *__restrict__ pairs, PairSel sel,
                                                  const int32_t *__restrict__ req_aa1,
                                                  const int32_t *__restrict__ req_aas, int band_width,
                                                  double cluster_thd, uint32_t *__restrict__ gscratch,
-                                                 uint32_t gscratch_stride, uint32_t *__restrict__ n_wide,
-                                                 uint32_t *__restrict__ err) {
+                                                 uint32_t gscratch_stride, uint32_t gscratch_cells,
+                                                 uint32_t *__restrict__ n_wide, uint32_t *__restrict__ err) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_wide = 0u;   // (pairs that the 16-lane aligner, which runs next, leaves to align_kernel)
-    __shared__ uint32_t diag[CAP];
+    constexpr bool kWideCell = sizeof(Cell) == 8;
+    constexpr int kHalf = (int)sizeof(Cell) * 4;
+    __shared__ Cell diag[CAP];
     __shared__ uint32_t taap[kNAA1 * kNAA1 + 7];
     __shared__ uint32_t abeg[kNAA1 * kNAA1 + 7];
     __shared__ uint16_t alist[CAP];
@@ -1383,11 +1451,11 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
         const int d_lo = req_aa1[k1r] - 1 >= 0 ? req_aa1[k1r] - 1 : 0;
         const int d_hi = nall - d_lo;
         const int n_d = d_hi >= d_lo ? d_hi - d_lo + 1 : 0;
-        const bool big = (uint32_t)n_d > CAP || (uint32_t)len1 > CAP;
-        uint32_t *dg = big ? gscratch + (size_t)blockIdx.x * gscratch_stride : diag;
-        // the query's 2-mer position lists (global scratch tail for oversized queries)
-        uint32_t *al_big = big ? dg + 2 * (gscratch_stride / 3) : nullptr;  // stride = 3 x (longest sequence, rounded up)
-        for (int i = lane; i < n_d; i += 64) dg[i] = 0u;
+        const bool big = kWideCell || (uint32_t)n_d > CAP || (uint32_t)len1 > CAP;
+        Cell *dg = big ? reinterpret_cast<Cell *>(gscratch + (size_t)blockIdx.x * gscratch_stride) : diag;
+        // the query's 2-mer position lists (global scratch tail for oversized queries: behind 2 x cells diagonals)
+        uint32_t *al_big = big ? reinterpret_cast<uint32_t *>(dg + 2 * (size_t)gscratch_cells) : nullptr;
+        for (int i = lane; i < n_d; i += 64) dg[i] = Cell(0);
         for (int c = lane; c < N2; c += 64) taap[c] = 0u;
         __syncthreads();
         const int last1 = len1 - S.kd, last2 = len2 - S.kd;
@@ -1416,7 +1484,7 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
             int cpx;
             const int c = kd_code(S, s2, i, &cpx);
             if (c < 0) continue;
-            const uint32_t inc = 1u | ((uint32_t)cpx << 16);
+            const Cell inc = Cell(1) | (Cell((uint32_t)cpx) << kHalf);
             const uint32_t b = abeg[c], e = b + taap[c];
             for (uint32_t t = b; t < e; ++t) {
                 const int j = big ? (int)al_big[t] : (int)alist[t];
@@ -2100,9 +2168,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         });
         for (uint32_t m : mx) max_len = std::max(max_len, m);
     }
-    if (max_len > (nt ? kMaxLen / 2 : kMaxLen)) {  // (the 4-mer complexity weights need 18 bits beyond 16383)
-        pgx_set_error("pgx_cluster_greedy: sequence of %u residues exceeds the supported maximum %u", max_len,
-                      nt ? kMaxLen / 2 : kMaxLen);
+    if (max_len > kMaxLen) {
+        pgx_set_error("pgx_cluster_greedy: sequence of %u residues exceeds the supported maximum %u", max_len, kMaxLen);
         return PGX_ERR_CAPACITY;
     }
     // stable counting sort by descending length: a histogram per thread over its share of the input, then
@@ -2256,20 +2323,25 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             std::min<uint64_t>(h_off[std::min(n, window_cap)], (uint64_t)kMaxChunks * std::max<uint64_t>(chunk_words, max_len)));
     PGX_REQUIRE(max_window_words < 0xFFFFFFF0ull, "window too large");
     const bool need_gscratch = (uint64_t)max_len * 2 > kDiagLdsSmall;
-    const uint32_t diag_grid = 8192, align_grid = 1024;  // diag: one wave per pair, ~11 workgroups fit a CU
-    const uint32_t gs_stride = 3u * ((max_len + 64u) & ~63u);  // per workgroup: 2 L diagonals + L query positions
+    const uint32_t packed_len = nt ? kPackedLenNt : kPackedLenAa;   // queries beyond this: 64-bit histogram cells
+    const uint32_t gs_cells = (max_len + 64u) & ~63u;
+    // per workgroup: 2 L diagonals (one or two words each) + L query positions
+    const uint32_t gs_stride = (max_len > packed_len ? 5u : 3u) * gs_cells;
+    // diag: one wave per pair, ~11 workgroups fit a CU; giant sequences: fewer workgroups, at most ~4 GB of scratch
+    const uint32_t diag_grid = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(8192, (4ull << 30) / ((uint64_t)gs_stride * 4)));
+    const uint32_t align_grid = 1024;
 
     DevBuf d_res, d_off, d_len, d_wcode, d_wmult, d_wcnt, d_aa1, d_aas, d_aan, d_lines, d_pool[2], d_idx,
         d_newbits, d_touched, d_first, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
         d_ulist, d_new_list, d_flags, d_gscratch, d_order, d_list, d_gather, d_pk, d_pkoff,
         d_counters2, d_best2, d_flags2, d_pairsW2, d_gscratch2,   // second set of a window's own state (see `overlap`)
-        d_thr;
+        d_thr, d_hugewords;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_lines,
                          &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_best_own, &d_rcvis,
                          &d_counters, &d_visits, &d_pairsW, &d_pairsK, &d_blk_list, &d_ulist, &d_new_list, &d_flags,
                          &d_gscratch, &d_order, &d_list, &d_gather, &d_pk, &d_pkoff,
-                         &d_counters2, &d_best2, &d_flags2, &d_pairsW2, &d_gscratch2, &d_thr};
+                         &d_counters2, &d_best2, &d_flags2, &d_pairsW2, &d_gscratch2, &d_thr, &d_hugewords};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -2384,14 +2456,25 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         };
         const uint32_t k32 = first_with_words_le(32768), k8 = first_with_words_le(8192),
                        k2 = first_with_words_le(2048), k5 = first_with_words_le(512);
-        PGX_REQUIRE(k32 == 0, "sequence too long for the word sorter");
         int rc;
         uint8_t *r8 = d_res.as<uint8_t>(); uint64_t *o64 = d_off.as<uint64_t>(); uint32_t *l32 = d_len.as<uint32_t>();
         uint32_t *wc = d_wcode.as<uint32_t>(); uint16_t *wm = d_wmult.as<uint16_t>(); uint32_t *wn = d_wcnt.as<uint32_t>();
         const int base = nt ? 4 : kNAA1;
         for (uint32_t half = 0; half < (both ? 2u : 1u); ++half) {  // the reverse complements have the same lengths
             const uint32_t o = half * n;
-            if ((rc = launch_words<32768, 1024>(ctx, st, r8, o64, l32, o, o + k8, wl, base, nt, wc, wm, wn))) return rc;
+            if (k32) {   // giant sequences (more than 32768 words): a table in global memory, a few at a time
+                uint32_t slots = 65536;
+                while (slots < 2u * max_len) slots *= 2;
+                const uint32_t per_launch = std::min(k32, std::max(1u, (uint32_t)((256ull << 20) / ((uint64_t)slots * 8))));
+                PGX_HIP(d_hugewords.alloc((size_t)per_launch * slots * 8));
+                ProfScope prof(ctx, "words_kernel", st);
+                for (uint32_t a = 0; a < k32; a += per_launch)
+                    words_huge_kernel<<<std::min(per_launch, k32 - a), 1024, 0, st>>>(r8, o64, l32, o + a, o + std::min(k32, a + per_launch), wl, base,
+                                                                                       nt, d_hugewords.as<uint32_t>(), slots, wc, wm, wn,
+                                                                                       d_counters.as<uint32_t>() + C_ERR);
+                LAUNCH_CHECK();
+            }
+            if ((rc = launch_words<32768, 1024>(ctx, st, r8, o64, l32, o + k32, o + k8, wl, base, nt, wc, wm, wn))) return rc;
             if ((rc = launch_words<8192, 1024>(ctx, st, r8, o64, l32, o + k8, o + k2, wl, base, nt, wc, wm, wn))) return rc;
             if ((rc = launch_words_hash<2048, 256>(ctx, st, r8, o64, l32, o + k2, o + k5, wl, base, nt, wc, wm, wn))) return rc;
             if ((rc = launch_words_hash<512, 128>(ctx, st, r8, o64, l32, o + k5, o + n, wl, base, nt, wc, wm, wn))) return rc;
@@ -2476,11 +2559,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         }
     };
     auto window_error = [&](uint32_t e, uint32_t at) {   // (the word is the OR over all processes in the record-sharded mode)
-        pgx_set_error("pgx_cluster_greedy: capacity failure in the window at %u%s:%s%s%s%s%s", at,
+        pgx_set_error("pgx_cluster_greedy: capacity failure in the window at %u%s:%s%s%s%s%s%s", at,
                       P->exchange ? " (on this or another process)" : "",
                       e & E_TOUCHED ? " append scratch list full;" : "", e & E_POOL ? " overflow pool of the word index full;" : "",
                       e & E_TABLE ? " exact table of the filter overflowed;" : "",
-                      e & E_BAND ? " alignment band wider than 64 diagonals;" : "", e & E_PAIRS ? " candidate pair buffer overflow;" : "");
+                      e & E_BAND ? " alignment band wider than 64 diagonals;" : "", e & E_PAIRS ? " candidate pair buffer overflow;" : "",
+                      e & E_WORDMULT ? " a word occurs more than 65535 times in one sequence;" : "");
     };
     const bool trace = std::getenv("PGX_TRACE") != nullptr;
     const uint32_t filter_grid = 4096u;
@@ -2588,9 +2672,10 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             const uint32_t ag = grid_hint ? std::min(align_grid, (grid_hint + 15) / 16) : align_grid;
             {
                 ProfScope prof(ctx, "diag_kernel", st);
-                auto kern = h_len[b0] <= kDiagLdsSmall ? diag_kernel<kDiagLdsSmall> : diag_kernel<kDiagLdsCap>;
+                auto kern = h_len[b0] > packed_len ? diag_kernel<64, unsigned long long>
+                            : (h_len[b0] <= kDiagLdsSmall ? diag_kernel<kDiagLdsSmall, uint32_t> : diag_kernel<kDiagLdsCap, uint32_t>);
                 kern<<<dg, 64, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
-                                        P->band_width, P->identity, d_gs, gs_stride, dc + C_WIDE, dc + C_ERR);
+                                        P->band_width, P->identity, d_gs, gs_stride, gs_cells, dc + C_WIDE, dc + C_ERR);
             }
             LAUNCH_CHECK();
             {

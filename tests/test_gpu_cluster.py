@@ -62,6 +62,37 @@ def test_edge_cases(gpu_ctx):
             raise AssertionError('%s: %s' % (name, e))
 
 
+def test_giant_sequences(gpu_ctx):
+    """Sequences beyond 32,767 residues (16,383 nucleotides) -- a handful of giant proteins exist, and cd-hit accepts
+    them -- take a word table in global memory and 64-bit cells in the diagonal histogram; everything else is the
+    ordinary path. Against the oracle, together with ordinary sequences. Only a word that occurs more than 65,535
+    times in ONE sequence is refused (multiplicities are kept in 16 bits)."""
+    from pangenomix_amd._native import PgxError
+    rng = np.random.default_rng(41)
+    g = rand_seq(rng, 41000)
+    seqs = [g, mutate(rng, g, 1200), mutate(rng, g[:36000], 9000), rand_seq(rng, 33500), g[:33000]]
+    seqs += [rand_seq(rng, 300) for _ in range(5)] + [mutate(rng, seqs[-1], 10)]
+    res, off = pack(seqs)
+    p = params()
+    got = gpu_ctx.cluster_greedy(res, off, p)
+    assert_same(got, oracle.cluster_greedy(res, off, p))
+    assert got[0][0] == got[0][1] == got[0][4] and got[0][3] != got[0][0]
+    from test_cluster_oracle import nt_params, rand_nt, revcomp
+
+    def mutate_nt(seq, k):
+        s_ = list(seq)
+        for pos in rng.choice(len(s_), size=k, replace=False):
+            s_[pos] = 'ACGT'[('ACGT'.index(s_[pos]) + 1 + int(rng.integers(0, 3))) % 4]
+        return ''.join(s_)
+    nt = rand_nt(rng, 21000)
+    nts = [nt, mutate_nt(nt, 500), revcomp(nt[:18000]), rand_nt(rng, 17000), rand_nt(rng, 200)]
+    res, off = pack(nts)
+    assert_same_nt(gpu_ctx.cluster_greedy(res, off, nt_params()), oracle.cluster_greedy(res, off, nt_params()))
+    res, off = pack(['A' * 70000, rand_seq(rng, 100)])
+    with pytest.raises(PgxError, match='more than 65535 times'):
+        gpu_ctx.cluster_greedy(res, off, p)
+
+
 def test_family_resolved_inside_one_sweep(gpu_ctx):
     """Many near-identical sequences of one length in one sweep: the in-batch resolution
     must still pick the first accepted representative in order."""
@@ -373,8 +404,8 @@ def test_errors_are_reported_and_leave_the_context_usable(gpu_ctx):
     good = pack([rand_seq(rng, 200) for _ in range(50)])
     p = params()
     want = oracle.cluster_greedy(good[0], good[1], p)
-    # a sequence beyond the supported length
-    res, off = pack([rand_seq(rng, 40000), rand_seq(rng, 100)])
+    # a sequence beyond the supported length (4 M residues; giant proteins of tens of thousands are fine: test_giant_sequences)
+    res, off = pack([rand_seq(rng, (1 << 22) + 1), rand_seq(rng, 100)])
     with pytest.raises(PgxError, match='exceeds the supported maximum'):
         gpu_ctx.cluster_greedy(res, off, p)
     assert_same(gpu_ctx.cluster_greedy(*good, p), want)
