@@ -808,7 +808,9 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     __shared__ uint4 s_stage[4][64];
     if (NEWONLY && *A.d_round_lo >= *A.d_round_hi) return;
     if (A.qlist && blockIdx.x * 4u >= (A.ns > A.nbq ? 2u : 1u) * *A.d_nq) return;   // (block mode: few members)
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // (wave-uniform by construction; saying so keeps what depends on it -- the member's slot, its state and offsets -- in
+    // scalar registers and scalar loads)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     if (threadIdx.x == 0) s_visits = 0ull;
     __syncthreads();
     const FilterWave W{s_bucket[wave], s_hrep[wave], s_hcnt[wave], s_hminc[wave], s_lq[wave], s_pref[wave]};
@@ -840,21 +842,44 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
     };
     FTimer ft{};
     ft.start();
-    for (uint32_t s = blockIdx.x * 4 + wave; s < n_slots; s += gridDim.x * 4) {
+    // A member's state and offsets: five independent loads that everything else waits for. The waves of this kernel
+    // are chains of dependent memory round trips (state -> words -> map probes -> lines -> best key), four waves per
+    // SIMD to hide them behind: the NEXT member's state is fetched while the current member is walked, and the best
+    // key (read when candidates are emitted) comes with it.
+    struct Member { uint32_t ql, nw; int32_t t0; uint64_t o; unsigned long long best; uint8_t done; bool valid, rstrand; };
+    auto load_member = [&](uint32_t s) -> Member {
+        Member m{};
+        if (s >= n_slots) return m;
         // window slot -> member, strand (block mode: slots enumerate the block list, then its reverse strands)
         const uint32_t half = A.qlist ? n_list : A.nbq;
-        const bool rstrand = s >= half;
-        const uint32_t ql = A.qlist ? A.qlist[rstrand ? s - half : s] - A.b0 : (rstrand ? s - half : s);
-        if (A.shard_count > 1 && !A.qlist && ql % A.shard_count != A.shard_index) continue;   // another process's member
-        if (A.done[ql] == 2) continue;                    // placed by an earlier chunk's sweep (memory-chunked rule)
+        m.rstrand = s >= half;
+        m.ql = A.qlist ? A.qlist[m.rstrand ? s - half : s] - A.b0 : (m.rstrand ? s - half : s);
+        if (A.shard_count > 1 && !A.qlist && m.ql % A.shard_count != A.shard_index) return m;   // another process's member
+        const uint32_t q = A.b0 + m.ql, k = m.rstrand ? S.n_fwd + q : q;
+        m.done = A.done[m.ql];
+        m.t0 = A.req_aan[q];
+        m.o = S.off[k];
+        m.nw = S.wcnt[k];
+        m.best = NEWONLY ? A.best[m.ql] : kNoBest;
+        m.valid = m.done != 2;                            // (2: placed by an earlier chunk's sweep, memory-chunked rule)
+        return m;
+    };
+    const uint32_t s_step = gridDim.x * 4;
+    Member nxt = load_member(blockIdx.x * 4 + wave);
+    for (uint32_t s = blockIdx.x * 4 + wave; s < n_slots; s += s_step) {
+        const Member me = nxt;
+        nxt = load_member(s + s_step);
+        if (!me.valid) continue;
+        const bool rstrand = me.rstrand;
+        const uint32_t ql = me.ql;
         const uint32_t q = A.b0 + ql;                     // the query (real sequence); candidates are r < q
         const uint32_t k = rstrand ? S.n_fwd + q : q;     // the strand walked
-        const bool count_only = NEWONLY && A.done[ql];
+        const bool count_only = NEWONLY && me.done;
         const uint32_t seg = NEWONLY ? seg_of(ql, A.nbq) : 0u;
-        const int32_t t0 = A.req_aan[q];
+        const int32_t t0 = me.t0;
         const uint32_t thr = t0 > 1 ? (uint32_t)t0 : 1u;
-        const uint64_t o = S.off[k];
-        const uint32_t nw = S.wcnt[k];
+        const uint64_t o = me.o;
+        const uint32_t nw = me.nw;
         uint32_t visits = 0;
         bool hot = false, full = false;
         Marked marked{0u, 0u, 0u, false};
@@ -884,7 +909,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
                 }
                 if (NEWONLY && emit) {   // only candidates whose key can still beat the member's current best
                     const unsigned long long key = ((unsigned long long)rstrand << 63) | ((unsigned long long)mc << 32) | r;
-                    const unsigned long long bo = A.best[ql];
+                    const unsigned long long bo = me.best;
                     emit = bo == kNoBest || key <= bo;
                 }
                 const unsigned long long em = __ballot(emit);
