@@ -794,11 +794,11 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
 }
 
 template <bool NT, bool NEWONLY>
-__global__ __launch_bounds__(256) void filter_kernel(DevSeqs S, FilterArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void filter_kernel(DevSeqs S, FilterArgs A) {
     // passes over a round's entries (proteins): the exact table first (512 slots), the buckets only for what
     // overflows it (256 are enough there: thresholds of long members are far above what chance hits add up to)
-    constexpr int FB = NEWONLY && !NT ? 256 : kFB;
-    constexpr int FH = NT ? kFHNt : (NEWONLY ? 2 * kFH : kFH);
+    constexpr int FB = NT ? kFB : (NEWONLY ? 256 : 512);
+    constexpr int FH = NT ? kFHNt : kFH;
     __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][FB];
     __shared__ uint32_t s_hrep[4][FH], s_hcnt[4][FH], s_hminc[4][FH];
     __shared__ uint4 s_lq[4][64];
@@ -1628,7 +1628,7 @@ __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__
 //   * border cells (row 0 / column 0 of the DP matrix) are produced by the same lanes as
 //     forced values, so interior cells never special-case their neighbours.
 // ----------------------------------------------------------------------------------------
-// LDS bytes per pair: a template parameter (1024 / 2048 / 4096), chosen per window from its longest query. The
+// LDS bytes per pair: a template parameter (1024 / 1536 / 2048 / 3072 / 4096), chosen per window from its longest query. The
 // kernel is bound by each pair's dependent chain, so what counts is waves per SIMD: 30 KB of LDS per workgroup
 // with 1 KB slots = five, 78 KB with 4 KB slots = two (17.8 -> 8.8 ms per step for the windows of cfg-3s that fit).
 // len1 + len2 <= slot - 96 is handled here (both sequences, 6-padded, fit the slot); the rest, and bands over 32
@@ -2669,7 +2669,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // the general (int64, one pair per wave) aligner is only needed when some pair of this
         // window cannot use the 16-lane fast path: query length + longest sequence, or the band
         // LDS slot per pair of the 16-lane aligner: sized for two sequences as long as the window's longest query
-        const int a16_slot = 2 * (int)h_len[b0] <= 1024 - 96 ? 1024 : (2 * (int)h_len[b0] <= 2048 - 96 ? 2048 : kA16MaxSlot);
+        const int two_len = 2 * (int)h_len[b0];
+        const int a16_slot = two_len <= 1024 - 96 ? 1024 : (two_len <= 1536 - 96 ? 1536 : (two_len <= 2048 - 96 ? 2048 : (two_len <= 3072 - 96 ? 3072 : kA16MaxSlot)));
         Pair *pairsW = (set ? d_pairsW2 : d_pairsW).as<Pair>();
         FilterArgs FA{};
         FA.lines = d_lines.as<IndexLine>(); FA.pool = d_poolp; FA.newbits = d_newbits.as<uint32_t>();
@@ -2697,15 +2698,18 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             const uint32_t ag = grid_hint ? std::min(align_grid, (grid_hint + 15) / 16) : align_grid;
             {
                 ProfScope prof(ctx, "diag_kernel", st);
+                // (LDS by the window's longest query: 512 positions give six waves per SIMD, 1024 four, 2048 two and a half)
                 auto kern = h_len[b0] > packed_len ? diag_kernel<64, unsigned long long>
-                            : (h_len[b0] <= kDiagLdsSmall ? diag_kernel<kDiagLdsSmall, uint32_t> : diag_kernel<kDiagLdsCap, uint32_t>);
+                            : (h_len[b0] <= kDiagLdsSmall ? diag_kernel<kDiagLdsSmall, uint32_t>
+                               : (h_len[b0] <= 2 * kDiagLdsSmall ? diag_kernel<2 * kDiagLdsSmall, uint32_t> : diag_kernel<kDiagLdsCap, uint32_t>));
                 kern<<<dg, 64, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), d_aas.as<int32_t>(),
                                         P->band_width, P->identity, d_gs, gs_stride, gs_cells, dc + C_WIDE, dc + C_ERR);
             }
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "align_kernel", st);
-                auto kern = a16_slot == 1024 ? align16_kernel<1024> : (a16_slot == 2048 ? align16_kernel<2048> : align16_kernel<kA16MaxSlot>);
+                auto kern = a16_slot == 1024 ? align16_kernel<1024> : (a16_slot == 1536 ? align16_kernel<1536> : (a16_slot == 2048 ? align16_kernel<2048>
+                            : (a16_slot == 3072 ? align16_kernel<3072> : align16_kernel<kA16MaxSlot>)));
                 kern<<<ag, 256, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, dc + C_WIDE);
                 align_kernel<<<grid_hint ? std::min(align_grid, (grid_hint + 3) / 4) : align_grid, 256, 0, st>>>(
                     DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, 1, a16_slot - 96, dc + C_WIDE);
