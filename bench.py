@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # gfx950 spec, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0   # aggregate L2, same guide
-PMC_SUMMARY = os.path.join('profiles', 'r02_pmc_summary_cfg3s.json')
+PMC_SUMMARY = os.path.join('profiles', 'r03_pmc_summary_cfg3s.json')
 
 
 def log(*a):

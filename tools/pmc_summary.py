@@ -1,10 +1,10 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc passes into profiles/r02_pmc_summary_cfg3s.json (HBM traffic per launch).
+"""Summarise rocprofv3 --pmc passes into profiles/r03_pmc_summary_cfg3s.json (HBM traffic per launch).
 
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 0 --skip-cpu --only all
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ... (same)
-  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r02_pmc_summary_cfg3s.json
+  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r03_pmc_summary_cfg3s.json
 
 FETCH_SIZE / WRITE_SIZE are in KiB and cannot share a pass (TCC slots). On gfx950 FETCH_SIZE
 reports exactly half of the bytes of a wide coalesced (16 B/lane) streaming read
