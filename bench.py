@@ -173,7 +173,19 @@ def main():
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or 'RANK' in os.environ   # (torchrun with one rank rehearses RCCL)
     if use_dist:
-        dist.init_process_group('nccl', device_id=dev)
+        # (librccl prints a version banner on STDOUT when it initialises: it goes to stderr, stdout stays the one JSON line)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', device_id=dev)
+            t_ = torch.zeros(1, device=dev)
+            dist.all_reduce(t_)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     sharded = use_dist and args.shard == 'records'
     workload = args.workload or ('cfg-4' if world > 1 else 'cfg-3s')
     ctx = _native.Context(local_rank)
