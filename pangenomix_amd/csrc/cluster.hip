@@ -462,7 +462,7 @@ __device__ __forceinline__ uint32_t line_len_prev(const IndexLine &L) { return ~
 // ever visits entries of representatives BEFORE it, all of which are in its own segment or an earlier one; with one
 // bit per code half of the marked words of a member (a line read each) lead to later representatives only -- with
 // kSegs bits an eighth. Setting the bits of segments seg..kSegs-1 is ONE atomicOr, probing one load, as before.
-// [filter<new> 31.2 -> 22.1 ms per step on cfg-3s together with the 512-slot direct table.]
+// [filter<new> 31.2 -> 22.1 ms per step on cfg-3s together with filling the exact table directly from every slab.]
 constexpr uint32_t kSegs = 4;
 __device__ __forceinline__ uint32_t seg_of(uint32_t ql, uint32_t nbq) { return (uint32_t)(((uint64_t)ql * kSegs) / nbq); }
 struct Deferred { uint32_t code, pos, entry, pad; };
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void index_place_kernel(IndexLine *__restrict_
 // ----------------------------------------------------------------------------------------
 // One wave per window slot (a query strand). The wave walks the query's distinct words, one word per
 // lane and 64-byte line per word, and counts min(mult_q, mult_r) per representative r < q:
-//   pass 1  counts into 1024 hashed LDS buckets (one LDS atomic per posting entry). A bucket sums the
+//   pass 1  counts into hashed LDS buckets (one LDS atomic per posting entry; 256 to 1024 per wave). A bucket sums the
 //           counts of every representative that hashes to it, so it can only over-count: a
 //           representative whose bucket stays below the query's threshold is certainly no candidate.
 //           Nearly every entry a query meets is a chance hit of a single word and ends here.
@@ -646,8 +646,8 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
                                             bool &full, Marked &M, FTimer &ft, uint32_t seg, bool redo = false) {
     const uint32_t rmask = entry_rmask(S), fmax = entry_fmax(S);
     // NEWONLY, first walk: the representatives met go straight into the exact table -- no bucket pass, no second
-    // walk (a round adds few entries to a query's lists; the table of these kernels has 512 slots, so a member of up
-    // to ~1500 residues fits even when every marked word leads to another representative). If the table overflows,
+    // walk (a round adds few entries to a query's lists; with the segment bits a member of ~1000 residues meets some
+    // 140 representatives of a round, which the 256 slots hold). If the table overflows,
     // the walk is redone (`redo`) with the buckets, visits not counted again, and the exact passes per residue
     // class follow as for any other walk. [Direct only for members whose marked words fit ONE slab, 256 slots,
     // before: the quarter of the members beyond that paid a bucket walk and a whole second walk -- a third of the
@@ -795,8 +795,12 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
 
 template <bool NT, bool NEWONLY>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void filter_kernel(DevSeqs S, FilterArgs A) {
-    // passes over a round's entries (proteins): the exact table first (512 slots), the buckets only for what
-    // overflows it (256 are enough there: thresholds of long members are far above what chance hits add up to)
+    // FIVE waves per SIMD (96 VGPRs, <= 30.7 KB of LDS per workgroup): the waves of these kernels wait for memory 72 % of
+    // their cycles and a wave's loads return in order, so occupancy is what hides the waits (four -> five waves: round
+    // passes 22.0 -> 18.7 ms per step; six would spill 21 registers). Passes over a round's entries (proteins): the exact
+    // table first (256 slots), 256 buckets only for what overflows it (thresholds of long members are far above what
+    // chance hits add up to); the pass over the whole index: 512 buckets. (The attribute cannot be met by the nucleotide
+    // instantiations, whose exact table is 24 KB per wave: the compiler says so and gives them what fits.)
     constexpr int FB = NT ? kFB : (NEWONLY ? 256 : 512);
     constexpr int FH = NT ? kFHNt : kFH;
     __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][FB];
