@@ -794,13 +794,13 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
 }
 
 template <bool NT, bool NEWONLY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void filter_kernel(DevSeqs S, FilterArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT ? 1 : 5, 8))) void filter_kernel(DevSeqs S, FilterArgs A) {
     // FIVE waves per SIMD (96 VGPRs, <= 30.7 KB of LDS per workgroup): the waves of these kernels wait for memory 72 % of
     // their cycles and a wave's loads return in order, so occupancy is what hides the waits (four -> five waves: round
     // passes 22.0 -> 18.7 ms per step; six would spill 21 registers). Passes over a round's entries (proteins): the exact
     // table first (256 slots), 256 buckets only for what overflows it (thresholds of long members are far above what
-    // chance hits add up to); the pass over the whole index: 512 buckets. (The attribute cannot be met by the nucleotide
-    // instantiations, whose exact table is 24 KB per wave: the compiler says so and gives them what fits.)
+    // chance hits add up to); the pass over the whole index: 512 buckets. (The nucleotide instantiations, whose exact
+    // table is 24 KB per wave, run one wave per SIMD.)
     constexpr int FB = NT ? kFB : (NEWONLY ? 256 : 512);
     constexpr int FH = NT ? kFHNt : kFH;
     __shared__ __attribute__((aligned(16))) uint32_t s_bucket[4][FB];
