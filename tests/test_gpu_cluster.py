@@ -206,6 +206,41 @@ def test_build_cds_pangenome_end_to_end(tmp_path, gpu_ctx):
     assert len(dfa.index) == int((want[0] >= 0).sum())
 
 
+def test_whole_output_equals_the_step_by_step_path_fed_by_the_oracle(tmp_path, gpu_ctx, monkeypatch):
+    """Everything at once, byte for byte: build_cds_pangenome() as shipped -- native ingest + de-duplication, clustering
+    on the GPU, native .clstr / names / FASTA writers, array tables, .npz -- against the statement-by-statement Python
+    path (consolidate_seqs -> cluster_with_cdhit -> rename_genes_and_alleles -> build_genetic_feature_tables, each
+    pinned to the reference's own output by tests/test_host_golden.py) with the CPU ORACLE as its clustering step.
+    Every file of the output directory must be identical, the .npz files member for member."""
+    import filecmp
+    import os
+    from pangenomix_amd import cluster
+    from test_host_golden import assert_same_npz
+    ps = synth.ProteinSet(14, 350, 500, 120, 31)
+    paths = ps.write_faa(str(tmp_path / 'genomes'))
+    out_gpu, out_ref = tmp_path / 'gpu', tmp_path / 'ref'
+    out_gpu.mkdir(), out_ref.mkdir()
+    pangenome.build_cds_pangenome(paths, str(out_gpu), name='E')
+
+    def oracle_cdhit(fasta_file, cdhit_out, cdhit_args={'-n': 5, '-c': 0.8}):
+        headers, residues, offsets, records = cluster.read_fasta_for_clustering(fasta_file)
+        cl, mem, iden, strand, n_clusters, _ = oracle.cluster_greedy(residues, offsets, cluster.params_from_cdhit_args(cdhit_args))
+        cluster.write_clstr(cdhit_out + '.clstr', headers, np.diff(offsets.astype(np.int64)), cl, mem, iden, strand)
+        with open(cdhit_out, 'w') as f:
+            for i in np.flatnonzero(mem == 0):
+                f.write(records[i])
+    monkeypatch.setattr(pangenome, '_native_pipeline', lambda *a, **k: None)      # the step-by-step path
+    monkeypatch.setattr(pangenome, 'cluster_with_cdhit', oracle_cdhit)
+    pangenome.build_cds_pangenome(paths, str(out_ref), name='E')
+    names = sorted(os.listdir(out_ref))
+    assert names == sorted(os.listdir(out_gpu)) and len(names) == 9
+    for f in names:
+        if f.endswith('.npz'):
+            assert_same_npz(str(out_gpu / f), str(out_ref / f))
+        else:
+            assert filecmp.cmp(str(out_gpu / f), str(out_ref / f), shallow=False), f
+
+
 # ---- K2: nucleotide rules (cd-hit-est), both strands ---------------------------------------------
 from test_cluster_oracle import nt_params, rand_nt, revcomp   # noqa: E402
 
@@ -508,3 +543,41 @@ def test_overlapped_windows_match_the_serial_loop(window, gpu_ctx, monkeypatch):
     monkeypatch.delenv('PGX_NO_OVERLAP')
     for _ in range(3):
         assert_same(gpu_ctx.cluster_greedy(res, off, p), want)
+
+
+def test_whole_noncoding_output_equals_the_step_by_step_path_fed_by_the_oracle(tmp_path, gpu_ctx, monkeypatch, golden_dir):
+    """The same for build_noncoding_pangenome() (nucleotide rules, both strands): every output file of the shipped
+    path equals the statement-by-statement path with the CPU oracle as its clustering step."""
+    import filecmp
+    import os
+    import shutil
+    from pangenomix_amd import cluster
+    from test_host_golden import assert_same_npz
+    outs = {}
+    for tag in ('gpu', 'ref'):
+        gdir = tmp_path / tag / 'genomes'
+        shutil.copytree(os.path.join(golden_dir, 'noncoding', 'in'), gdir)
+        pairs = sorted(pangenome.find_matching_genome_files(str(gdir), str(gdir)))
+        out = tmp_path / tag / 'out'
+        out.mkdir()
+        if tag == 'ref':
+            def oracle_cdhit(fasta_file, cdhit_out, cdhit_args={'-n': 5, '-c': 0.8}):
+                nt = fasta_file[-4:].lower() == '.fna'
+                headers, residues, offsets, records = cluster.read_fasta_for_clustering(fasta_file)
+                p = cluster.params_from_cdhit_args(cdhit_args, 'nt' if nt else 'aa')
+                cl, mem, iden, strand, n_clusters, _ = oracle.cluster_greedy(residues, offsets, p)
+                cluster.write_clstr(cdhit_out + '.clstr', headers, np.diff(offsets.astype(np.int64)), cl, mem, iden, strand, nt)
+                with open(cdhit_out, 'w') as f:
+                    for i in np.flatnonzero(mem == 0):
+                        f.write(records[i])
+            monkeypatch.setattr(pangenome, '_native_pipeline', lambda *a, **k: None)
+            monkeypatch.setattr(pangenome, 'cluster_with_cdhit', oracle_cdhit)
+        pangenome.build_noncoding_pangenome(pairs, str(out), name='NC')
+        outs[tag] = out
+    names = sorted(os.listdir(outs['ref']))
+    assert names == sorted(os.listdir(outs['gpu']))
+    for f in names:
+        if f.endswith('.npz'):
+            assert_same_npz(str(outs['gpu'] / f), str(outs['ref'] / f))
+        else:
+            assert filecmp.cmp(str(outs['gpu'] / f), str(outs['ref'] / f), shallow=False), f
