@@ -676,8 +676,9 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
                 return;
             }
             if (thr == 1u) { hot = true; return; }    // one shared word makes a candidate: nothing to bound
-            const uint32_t old = atomicAdd(&W.bucket[b], c);
-            hot |= old + c >= thr;
+            atomicAdd(&W.bucket[b], c);             // (no result needed here: `hot` comes from one look at the buckets
+                                                    // after the walk -- a returning atomic per visit made every visit wait
+                                                    // for the one before, 130 per lane on a 4000-genome index)
         } else {
             if (thr > 1u && W.bucket[b] < thr) return;
             if (((((r ^ (r >> 15)) * 0x85EBCA6Bu) >> 9) & (class_k - 1u)) != class_j) return;
@@ -722,11 +723,26 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             W.lq[lane] = make_uint4(la.y + 1u + (from - kInline), incl - cnt_l, code, mq);
             W.pref[lane] = incl;
             wave_lds_sync();
-            for (uint32_t t = lane; t < total; t += 64) {
-                uint32_t a = 0, b = 63;                    // the list that holds entry t: first prefix > t
-                while (a < b) { const uint32_t mid = (a + b) >> 1; if (W.pref[mid] > t) b = mid; else a = mid + 1; }
-                const uint4 it = W.lq[a];
-                entry_visit(A.pool[it.x + (t - it.y)], it.z, it.w);
+            // (kPoolAhead entries per lane are located and LOADED before any is visited: a list of a 4000-genome index
+            // has 25 entries, 14 of them in the pool, and one dependent pool read per visit made the pass over the
+            // whole index half of the run on cfg-4)
+            constexpr uint32_t kPoolAhead = NEWONLY ? 1 : 4;   // (the round passes have no registers to spare: one)
+            for (uint32_t t0 = lane; t0 < total; t0 += 64u * kPoolAhead) {
+                uint32_t ent[kPoolAhead], ecode[kPoolAhead], emq[kPoolAhead];
+#pragma unroll
+                for (uint32_t u = 0; u < kPoolAhead; ++u) {
+                    const uint32_t t = t0 + 64u * u;
+                    ent[u] = 0u; ecode[u] = 0u; emq[u] = 0u;     // (mq == 0: no entry)
+                    if (t < total) {
+                        uint32_t a = 0, b = 63;                // the list that holds entry t: first prefix > t
+                        while (a < b) { const uint32_t mid = (a + b) >> 1; if (W.pref[mid] > t) b = mid; else a = mid + 1; }
+                        const uint4 it = W.lq[a];
+                        ent[u] = A.pool[it.x + (t - it.y)]; ecode[u] = it.z; emq[u] = it.w;
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kPoolAhead; ++u)
+                    if (emq[u]) entry_visit(ent[u], ecode[u], emq[u]);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -946,6 +962,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT ? 1 : 5,
                 if (lane == 0) atomicAdd(&g_ftime[13], 1ull);
 #endif
             }
+        }
+        if (!direct_done && !count_only && visits && thr > 1u) {   // did any bucket reach the threshold?
+            uint32_t mx = 0;
+            for (uint32_t i = lane * 4; i < (uint32_t)FB; i += 256) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&W.bucket[i]);
+                mx = max(max(mx, v.x), max(max(v.y, v.z), v.w));
+            }
+            hot = mx >= thr;
         }
 #ifdef PGX_FTIME
         if (!direct_done && __ballot(hot) && lane == 0) atomicAdd(&g_ftime[15], 1ull);

@@ -19,3 +19,13 @@ for k, v in sorted(d['kernels_ms_per_step'].items(), key=lambda kv: -kv[1]['ms']
 print('gpu stats', d['cluster']['stats']['gpu'])
 PY
 grep "windows" gpurun_out/${L}_bench.err | tail -2
+if [ -n "$CFG4" ]; then
+  timeout -k 10 600 python bench.py --workload cfg-4 --skip-cpu --skip-e2e --steps 2 --warmup 1 > gpurun_out/${L}_bench4.json 2> gpurun_out/${L}_bench4.err || { tail -5 gpurun_out/${L}_bench4.err; exit 1; }
+  python - <<PY
+import json
+d = json.load(open('gpurun_out/${L}_bench4.json'))
+print('cfg-4: value %.3f M proteins/s, cluster %.1f ms' % (d['value'] / 1e6, d['cluster']['ms']))
+for k, v in sorted(d['kernels_ms_per_step'].items(), key=lambda kv: -kv[1]['ms'])[:8]:
+    print('  %-26s %8.2f ms %5d' % (k, v['ms'], v['launches']))
+PY
+fi
