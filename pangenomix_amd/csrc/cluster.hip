@@ -702,6 +702,27 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
         // the lanes start at different entries of their lines: lists keep insertion order, so in a family (or with
         // few codes) entry j of every lane's list is the same representative -- 64 atomics on one LDS address
         const uint32_t n_in = hi_in > lo ? hi_in - lo : 0u;
+        if (!NEWONLY) {
+            // The pass over the whole index visits every inline entry: entry t of every lane in step t, each straight
+            // from its register (picking entry j of a line by ten selects was a third of this pass's instructions,
+            // which is what bounds it on a 4000-genome index: 12.8 k vector instructions per member for 17 k visits).
+            // The four lane groups take the entries in different rotations, so that a family's representative -- the
+            // same entry position in many lanes' lists -- meets at most a quarter of the lanes in one LDS atomic.
+            const uint32_t ents[kInline] = {lb.y, lb.z, lb.w, lc.x, lc.y, lc.z, lc.w, ld.x, ld.y, ld.z, ld.w};
+            const uint32_t grp = lane & 3u;
+            const unsigned long long most = __ballot(hi_in != 0u);
+            if (most) {
+#pragma unroll
+                for (uint32_t t = 0; t < kInline; ++t) {
+                    const uint32_t a = ents[t], b = ents[(t + 3u) % kInline], c2 = ents[(t + 6u) % kInline], d = ents[(t + 9u) % kInline];
+                    const uint32_t e = grp == 0u ? a : (grp == 1u ? b : (grp == 2u ? c2 : d));
+                    const uint32_t idx = grp == 0u ? t : (grp == 1u ? (t + 3u) % kInline : (grp == 2u ? (t + 6u) % kInline : (t + 9u) % kInline));
+                    if (idx < hi_in) entry_visit(e, code, mq);
+                }
+            }
+        } else {
+        // (a round's entries: a range of the line that starts anywhere)
+        // the lanes start at different entries of their lines
         uint32_t j = lo + ((lane * n_in) >> 6);
         for (uint32_t t = 0; t < n_in; ++t, j = j + 1u == hi_in ? lo : j + 1u) {
             uint32_t e = lb.y;                     // entry j, picked from the line's registers
@@ -709,6 +730,7 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             e = j == 5 ? lc.z : e; e = j == 6 ? lc.w : e; e = j == 7 ? ld.x : e; e = j == 8 ? ld.y : e;
             e = j == 9 ? ld.z : e; e = j == 10 ? ld.w : e;
             entry_visit(e, code, mq);
+        }
         }
         // lists longer than the line: their pool parts are flattened into one run of entries that the whole
         // wave walks, one entry per lane and step, whatever the lists' lengths (a list of one new entry
