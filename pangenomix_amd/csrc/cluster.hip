@@ -12,7 +12,7 @@
 // accepted representatives r < q (r = position in the sorted order = creation order).
 //
 // The word table of the sequential rule is kept on the device for the whole call as an INVERTED
-// INDEX, one 64-byte line per word code (list length + first entries; longer lists continue in a
+// INDEX, one 128-byte line per word code (list length + first 27 entries; longer lists continue in a
 // pool), appended to whenever representatives are confirmed. The short-word filter is QUERY-MAJOR:
 // one wave per query walks the lines of the query's words, so a query touches exactly the posting
 // entries the sequential rule visits.
@@ -429,25 +429,28 @@ __global__ __launch_bounds__(1024) void words_huge_kernel(const uint8_t *__restr
 // ----------------------------------------------------------------------------------------
 // The structure the sequential rule itself walks (its "word table": per word the representatives
 // that have it), kept for the whole call and grown in place:
-//   line[code] = { len, ovf, round, pending, e[11] }   (one 64-byte line: ONE memory transaction gives
-//                a query the list's length and its first 11 entries)
+//   line[code] = { len, ovf, round, pending, e[27] }   (one 128-byte line in two 64-byte halves: ONE memory transaction
+//                gives a query the list's length and its first 11 entries; the second half -- entries 11..26, the same
+//                L2 line -- is read only when a list reaches it. [64-byte lines with 11 entries until round 3: a
+//                4000-genome index has 25 entries per list, and the 14 in the overflow pool cost a 6-step search each.]
 //   entry      = sorted sequence index of the representative (low bits) | min(multiplicity of the word in
 //                it, field maximum) above them; the field maximum means "look it up in its word list"
-//   overflow   = entries 11.. live in pool[ovf + 1 ..], a contiguous array of capacity pool[ovf]
+//   overflow   = entries 27.. live in pool[ovf + 1 ..], a contiguous array of capacity pool[ovf]
 //                that is re-allocated with twice the need when it fills (bump allocation)
 //   round      = epoch << 32 | ~len_prev: the latest append round that touched the list and the list's
 //                length before that round, so that a pass can visit exactly the entries a round added (new
 //                representatives of the window). One 64-bit atomicMax per appended entry maintains it:
 //                a newer round beats an older one, and within a round the smallest position wins.
 // Entries keep no order (candidates are ordered by an explicit key).
-constexpr uint32_t kInline = 11;
-struct __attribute__((aligned(64))) IndexLine {
+constexpr uint32_t kInline = 27;     // entries in the line
+constexpr uint32_t kInlineA = 11;    // ... of which in its first 64 bytes
+struct __attribute__((aligned(128))) IndexLine {
     uint32_t len, ovf;
     unsigned long long round;
     uint32_t pending;
     uint32_t e[kInline];
 };
-static_assert(sizeof(IndexLine) == 64, "one line per word code");
+static_assert(sizeof(IndexLine) == 128, "one line per word code: two 64-byte halves");
 __device__ __forceinline__ uint32_t line_len_prev(const IndexLine &L) { return ~(uint32_t)L.round; }
 
 // Appending the representatives list[*d_lo .. *d_hi) as round `epoch`. 94 % of the lists a protein query meets
@@ -698,7 +701,7 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
         // line = { len, ovf, ~len_prev, epoch | pending, e0, e1, e2 | e3..e6 | e7..e10 }
         const uint32_t hi = la.x;
         const uint32_t lo = NEWONLY ? (la.w == A.epoch ? ~la.z : hi) : 0u;
-        const uint32_t hi_in = hi < kInline ? hi : kInline;
+        const uint32_t hi_in = hi < kInlineA ? hi : kInlineA;    // (first half of the line)
         // the lanes start at different entries of their lines: lists keep insertion order, so in a family (or with
         // few codes) entry j of every lane's list is the same representative -- 64 atomics on one LDS address
         const uint32_t n_in = hi_in > lo ? hi_in - lo : 0u;
@@ -708,17 +711,32 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             // which is what bounds it on a 4000-genome index: 12.8 k vector instructions per member for 17 k visits).
             // The four lane groups take the entries in different rotations, so that a family's representative -- the
             // same entry position in many lanes' lists -- meets at most a quarter of the lanes in one LDS atomic.
-            const uint32_t ents[kInline] = {lb.y, lb.z, lb.w, lc.x, lc.y, lc.z, lc.w, ld.x, ld.y, ld.z, ld.w};
             const uint32_t grp = lane & 3u;
-            const unsigned long long most = __ballot(hi_in != 0u);
-            if (most) {
+            if (__ballot(hi_in != 0u)) {
+                const uint32_t ents[kInlineA] = {lb.y, lb.z, lb.w, lc.x, lc.y, lc.z, lc.w, ld.x, ld.y, ld.z, ld.w};
 #pragma unroll
-                for (uint32_t t = 0; t < kInline; ++t) {
-                    const uint32_t a = ents[t], b = ents[(t + 3u) % kInline], c2 = ents[(t + 6u) % kInline], d = ents[(t + 9u) % kInline];
+                for (uint32_t t = 0; t < kInlineA; ++t) {
+                    const uint32_t a = ents[t], b = ents[(t + 3u) % kInlineA], c2 = ents[(t + 6u) % kInlineA], d = ents[(t + 9u) % kInlineA];
                     const uint32_t e = grp == 0u ? a : (grp == 1u ? b : (grp == 2u ? c2 : d));
-                    const uint32_t idx = grp == 0u ? t : (grp == 1u ? (t + 3u) % kInline : (grp == 2u ? (t + 6u) % kInline : (t + 9u) % kInline));
+                    const uint32_t idx = grp == 0u ? t : (grp == 1u ? (t + 3u) % kInlineA : (grp == 2u ? (t + 6u) % kInlineA : (t + 9u) % kInlineA));
                     if (idx < hi_in) entry_visit(e, code, mq);
                 }
+            }
+            // the second half of the line (entries 11 .. 26): read only when some lane's list reaches it -- the same
+            // 128-byte line, an L2 hit -- and walked the same way. [With 11 entries per line a 4000-genome index
+            // (25 entries per list) kept 14 of them in the overflow pool, whose walk costs a 6-step search per entry.]
+            if (__ballot(hi > kInlineA)) {
+                uint4 h0 = make_uint4(0u, 0u, 0u, 0u), h1 = h0, h2 = h0, h3 = h0;
+                if (hi > kInlineA) {
+                    const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + code);
+                    h0 = lp[4]; h1 = lp[5]; h2 = lp[6]; h3 = lp[7];
+                }
+                constexpr uint32_t kB = kInline - kInlineA;   // 16
+                const uint32_t hi_b = hi > kInlineA ? (hi < kInline ? hi : kInline) - kInlineA : 0u;
+                const uint32_t entsb[kB] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+#pragma unroll
+                for (uint32_t t = 0; t < kB; ++t)     // (no rotation here: what a family shares sits at the front of its lists)
+                    if (t < hi_b) entry_visit(entsb[t], code, mq);
             }
         } else {
         // (a round's entries: a range of the line that starts anywhere)
@@ -731,6 +749,10 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             e = j == 9 ? ld.z : e; e = j == 10 ? ld.w : e;
             entry_visit(e, code, mq);
         }
+        // ... and what the round added to the second half of the line
+        const uint32_t lo_b = lo > kInlineA ? lo : kInlineA, hi_b = hi < kInline ? hi : kInline;
+        for (uint32_t jb = lo_b; jb < hi_b; ++jb)     // (one entry as a rule: read where it is, the line is in L2)
+            entry_visit(A.lines[code].e[jb], code, mq);
         }
         // lists longer than the line: their pool parts are flattened into one run of entries that the whole
         // wave walks, one entry per lane and step, whatever the lists' lengths (a list of one new entry
@@ -748,7 +770,7 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             // (kPoolAhead entries per lane are located and LOADED before any is visited: a list of a 4000-genome index
             // has 25 entries, 14 of them in the pool, and one dependent pool read per visit made the pass over the
             // whole index half of the run on cfg-4)
-            constexpr uint32_t kPoolAhead = NEWONLY ? 1 : 4;   // (the round passes have no registers to spare: one)
+            constexpr uint32_t kPoolAhead = NEWONLY ? 1 : 2;   // (the round passes have no registers to spare: one)
             for (uint32_t t0 = lane; t0 < total; t0 += 64u * kPoolAhead) {
                 uint32_t ent[kPoolAhead], ecode[kPoolAhead], emq[kPoolAhead];
 #pragma unroll
@@ -2433,7 +2455,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_aa1.alloc((size_t)n * 4));
     PGX_HIP(d_aas.alloc((size_t)n * 4));
     PGX_HIP(d_aan.alloc((size_t)n * 4));
-    // the word index: all lines empty (one memset of n_codes * 64 B per call, e.g. 261 MB for protein 5-mers)
+    // the word index: all lines empty (one memset of n_codes * 128 B per call, e.g. 523 MB for protein 5-mers)
     PGX_HIP(d_lines.alloc((size_t)n_codes * sizeof(IndexLine)));
     PGX_HIP(hipMemsetAsync(d_lines.p, 0, (size_t)n_codes * sizeof(IndexLine), st));
     PGX_HIP(d_idx.alloc(16));
