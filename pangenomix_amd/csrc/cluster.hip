@@ -696,7 +696,8 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
         uint4 la = make_uint4(0u, 0u, 0u, 0u), lb = la, lc = la, ld = la;
         if (live) {
             const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + code);
-            la = lp[0]; lb = lp[1]; lc = lp[2]; ld = lp[3];
+            la = lp[0];
+            if (!NEWONLY) { lb = lp[1]; lc = lp[2]; ld = lp[3]; }   // (a round's pass reads the few entries it visits where they are)
         }
         // line = { len, ovf, ~len_prev, epoch | pending, e0, e1, e2 | e3..e6 | e7..e10 }
         const uint32_t hi = la.x;
@@ -739,20 +740,13 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
                     if (t < hi_b) entry_visit(entsb[t], code, mq);
             }
         } else {
-        // (a round's entries: a range of the line that starts anywhere)
-        // the lanes start at different entries of their lines
-        uint32_t j = lo + ((lane * n_in) >> 6);
-        for (uint32_t t = 0; t < n_in; ++t, j = j + 1u == hi_in ? lo : j + 1u) {
-            uint32_t e = lb.y;                     // entry j, picked from the line's registers
-            e = j == 1 ? lb.z : e; e = j == 2 ? lb.w : e; e = j == 3 ? lc.x : e; e = j == 4 ? lc.y : e;
-            e = j == 5 ? lc.z : e; e = j == 6 ? lc.w : e; e = j == 7 ? ld.x : e; e = j == 8 ? ld.y : e;
-            e = j == 9 ? ld.z : e; e = j == 10 ? ld.w : e;
-            entry_visit(e, code, mq);
-        }
-        // ... and what the round added to the second half of the line
-        const uint32_t lo_b = lo > kInlineA ? lo : kInlineA, hi_b = hi < kInline ? hi : kInline;
-        for (uint32_t jb = lo_b; jb < hi_b; ++jb)     // (one entry as a rule: read where it is, the line is in L2)
-            entry_visit(A.lines[code].e[jb], code, mq);
+        // A round's entries: a range of the line that starts anywhere, one or two entries as a rule. They are read
+        // where they are (the line's header has just been fetched: L2 hits) instead of holding the line's 27 entries in
+        // registers and picking by select chains.
+        (void)n_in;
+        const uint32_t hi_l = hi < kInline ? hi : kInline;
+        const uint32_t *le = reinterpret_cast<const uint32_t *>(A.lines + code) + 5;    // e[0]
+        for (uint32_t jb = lo; jb < hi_l; ++jb) entry_visit(le[jb], code, mq);
         }
         // lists longer than the line: their pool parts are flattened into one run of entries that the whole
         // wave walks, one entry per lane and step, whatever the lists' lengths (a list of one new entry
