@@ -752,7 +752,21 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
         // wave walks, one entry per lane and step, whatever the lists' lengths (a list of one new entry
         // and a list of thousands cost what their entries cost)
         const bool longl = hi > kInline && hi > lo;
-        if (__ballot(longl)) {
+        bool flatten = __ballot(longl) != 0ull;
+        if (NEWONLY && flatten) {
+            // a round adds one or two entries to a list, wherever the list ends: when no lane of the slab has more than
+            // four behind the line, each lane reads its own in place (on a 4000-genome index nearly every slab has lists
+            // that end in the pool, and the flattened walk's set-up -- a prefix scan, LDS records, a search per entry --
+            // was paid for a handful of entries)
+            const uint32_t from = lo > kInline ? lo : kInline;
+            const uint32_t cnt_l = longl ? hi - from : 0u;
+            if (!__ballot(cnt_l > 4u)) {
+                const uint32_t *pp = A.pool + la.y + 1u + (from - kInline);
+                for (uint32_t j2 = 0; j2 < cnt_l; ++j2) entry_visit(pp[j2], code, mq);
+                flatten = false;
+            }
+        }
+        if (flatten) {
             const uint32_t from = lo > kInline ? lo : kInline;
             const uint32_t cnt_l = longl ? hi - from : 0u;
             uint32_t incl = cnt_l;
