@@ -522,9 +522,14 @@ __global__ __launch_bounds__(256) void index_grow_kernel(IndexLine *__restrict__
         L.ovf = idx;
     }
 }
+// (It also clears the map of touched codes the NEXT append round will use -- there are two, used alternately; the one
+// cleared here was last read by the pass over the round before this one, which is complete -- instead of a launch of its own.)
 __global__ __launch_bounds__(256) void index_place_kernel(IndexLine *__restrict__ lines, uint32_t *__restrict__ pool,
                                                          const Deferred *__restrict__ deferred,
-                                                         const uint32_t *__restrict__ n_deferred, uint32_t deferred_cap) {
+                                                         const uint32_t *__restrict__ n_deferred, uint32_t deferred_cap,
+                                                         uint4 *__restrict__ next_map, uint32_t map_vec4) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < map_vec4; i += gridDim.x * blockDim.x)
+        next_map[i] = make_uint4(0u, 0u, 0u, 0u);
     const uint32_t n = min(*n_deferred, deferred_cap);
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         const Deferred d = deferred[t];
@@ -1096,6 +1101,11 @@ __global__ __launch_bounds__(256) void index_strike_kernel(DevSeqs S, const uint
 // ----------------------------------------------------------------------------------------
 // window state: open members, discovery of certain representatives, blocks
 // ----------------------------------------------------------------------------------------
+// counters: [0] pairs of the window, [1] pairs of the block, [2] begin of the pair range to evaluate,
+// [3] block size, [4] open members, [5] new representatives of the window (list length),
+// [6] begin of the current round's segment of that list, [7] touched codes of the round,
+// [8] error flag, [9] open members of the round
+enum { C_NW = 0, C_NK = 1, C_EVAL0 = 2, C_BLK = 3, C_OPEN = 4, C_NEW = 5, C_SEG0 = 6, C_TOUCH = 7, C_ERR = 8, C_ROUND_OPEN = 9, C_ZERO = 10, C_WIDE = 11, C_ROUND_OPEN2 = 12, C_COUNT = 16 };
 constexpr int kSelThreads = 1024;
 // Pick the next block: the first `block_cap` window members, in order, that are not final (`done`)
 // and have no accepted representative yet. One workgroup; thread t looks at members t, t + 1024, ...
@@ -1110,13 +1120,13 @@ __global__ __launch_bounds__(kSelThreads) void select_block_kernel(const unsigne
                                                                   uint32_t *__restrict__ counters,
                                                                   uint32_t *__restrict__ n_k,
                                                                   uint8_t *__restrict__ hascand_accepted,
-                                                                  uint32_t window_cap) {
+                                                                  uint32_t window_cap, uint32_t *__restrict__ base_counters) {
     constexpr uint32_t kTiles = kWindowMax / kSelThreads;      // 64
     __shared__ uint32_t s_pre[kTiles][16];                      // open members of tile j in the waves before wave w
     __shared__ uint32_t s_tile[kTiles + 1];                     // ... in the tiles before tile j
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t i = tid; i < 2 * window_cap / 8; i += kSelThreads) reinterpret_cast<unsigned long long *>(hascand_accepted)[i] = 0ull;
-    if (tid == 0) *n_k = 0u;
+    if (tid == 0) { *n_k = 0u; base_counters[C_TOUCH] = 0u; base_counters[C_EVAL0] = base_counters[C_NW]; }   // (the block's tentative append and pairs begin here)
     const uint32_t n_tiles = (nb + kSelThreads - 1) / kSelThreads;
     unsigned long long open = 0ull;                             // bit j: member j * 1024 + tid is open
 #pragma unroll 8
@@ -1163,12 +1173,19 @@ __global__ __launch_bounds__(kSelThreads) void select_block_kernel(const unsigne
 
 // Start of a discovery round: the window's still-open members (not final, no accepted
 // representative), and where the round's segment of the new-representative list begins.
+// (It also opens the round -- the pair range and list segment that the round's kernels work on begin here -- and
+// clears the counter the NEXT round's list will use: two counters, used alternately, instead of a launch of its own.)
 __global__ __launch_bounds__(256) void list_open_kernel(const unsigned long long *__restrict__ best,
                                                        const uint8_t *__restrict__ done, uint32_t b0, uint32_t nb,
-                                                       uint32_t *__restrict__ ulist, uint32_t *__restrict__ n_open) {
+                                                       uint32_t *__restrict__ ulist, uint32_t *__restrict__ c,
+                                                       uint32_t which) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0) {
+        c[C_EVAL0] = c[C_NW]; c[C_SEG0] = c[C_NEW]; c[C_TOUCH] = 0u;
+        c[which ? C_ROUND_OPEN : C_ROUND_OPEN2] = 0u;
+    }
     if (q >= nb) return;
-    if (!done[q] && best[q] == kNoBest) ulist[atomicAdd(n_open, 1u)] = b0 + q;
+    if (!done[q] && best[q] == kNoBest) ulist[atomicAdd(&c[which ? C_ROUND_OPEN2 : C_ROUND_OPEN], 1u)] = b0 + q;
 }
 // Discovery of certain representatives in time linear in the open members' words.
 //
@@ -1292,30 +1309,17 @@ __global__ __launch_bounds__(256) void thresholds_kernel(const uint32_t *__restr
     aa1[k] = tab[L]; aas[k] = tab[n_len + L]; aan[k] = tab[2 * n_len + L];
 }
 
-// (hipMemsetAsync between kernels left the stream idle for ~130 us each time -- 55 ms per run in the
-// first timeline of this design -- so the per-round clears are launches of our own)
-__global__ __launch_bounds__(256) void zero_kernel(uint4 *__restrict__ p, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-        p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
+// (hipMemsetAsync between kernels left the stream idle for ~130 us each time -- 55 ms per run in the first timeline of this
+// design -- so the per-round clears happen inside kernels of our own: index_place_kernel, list_open_kernel)
 // small bookkeeping kernels -----------------------------------------------------------------
-// counters: [0] pairs of the window, [1] pairs of the block, [2] begin of the pair range to evaluate,
-// [3] block size, [4] open members, [5] new representatives of the window (list length),
-// [6] begin of the current round's segment of that list, [7] touched codes of the round,
-// [8] error flag, [9] open members of the round
-enum { C_NW = 0, C_NK = 1, C_EVAL0 = 2, C_BLK = 3, C_OPEN = 4, C_NEW = 5, C_SEG0 = 6, C_TOUCH = 7, C_ERR = 8, C_ROUND_OPEN = 9, C_ZERO = 10, C_WIDE = 11, C_COUNT = 16 };
 
 // block members are final once the host has walked the block (final = 0: the block is given up, see the host)
-__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb, uint32_t final_) {
+// (begin != nullptr: the pass over the block's representatives begins -- no code touched yet, its pairs begin here)
+__global__ void retire_block_kernel(uint8_t *__restrict__ done, uint8_t *__restrict__ inblk, uint32_t nb, uint32_t final_,
+                                    uint32_t *__restrict__ begin) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q == 0 && begin) { begin[C_TOUCH] = 0u; begin[C_NK] = 0u; begin[C_EVAL0] = begin[C_NW]; }
     if (q < nb && inblk[q]) { done[q] = (uint8_t)final_; inblk[q] = 0; }
-}
-// start of a block's tentative append: no code touched yet, the block's pairs begin
-__global__ void block_begin_kernel(uint32_t *__restrict__ c) { c[C_TOUCH] = 0u; c[C_NK] = 0u; c[C_EVAL0] = c[C_NW]; }
-// start of a round: the pair range and list segment that the round's kernels work on begin here
-__global__ void round_begin_kernel(uint32_t *__restrict__ c) {
-    c[C_EVAL0] = c[C_NW]; c[C_SEG0] = c[C_NEW]; c[C_TOUCH] = 0u; c[C_ROUND_OPEN] = 0u;
 }
 // Start of a window: counters, best keys, reverse-strand visit counters and member flags in one launch.
 __global__ __launch_bounds__(256) void window_init_kernel(uint32_t *__restrict__ counters,
@@ -2469,7 +2473,8 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_idx.alloc(16));
     static_assert(kSegs == 4, "eight codes per word of the round's map");
     const uint32_t bm_words = (n_codes / 8 + 2 + 3) & ~3u;   // words of the round's map of touched codes
-    PGX_HIP(d_newbits.alloc((size_t)bm_words * 4 + 16));
+    PGX_HIP(d_newbits.alloc(2 * (size_t)bm_words * 4 + 16));          // two maps, used by alternate append rounds
+    PGX_HIP(hipMemsetAsync(d_newbits.p, 0, 2 * (size_t)bm_words * 4, st));
     PGX_HIP(d_touched.alloc((max_window_words + 16) * sizeof(Deferred)));   // entries set aside by an append round
     if (chunking && n > window_cap / 2) max_chunks = kMaxChunks;   // (smaller chunks later may need all of them)
     uint32_t tag_stride = 1;   // first-open tags: one record of tag_stride >= max_chunks words per code
@@ -2836,16 +2841,18 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // append list[*lo, *hi) to the index as round `epoch_idx` (the bit map of touched codes is the round's)
         auto index_append = [&](const uint32_t *list, const uint32_t *d_lo, const uint32_t *d_hi) -> int {
             ++epoch_idx;
-            zero_kernel<<<128, 256, 0, st>>>(d_newbits.as<uint4>(), (size_t)bm_words / 4);
+            uint32_t *const map = d_newbits.as<uint32_t>() + (size_t)(epoch_idx & 1u) * bm_words;   // (clear: index_place_kernel of the round before)
+            uint32_t *const next_map = d_newbits.as<uint32_t>() + (size_t)((epoch_idx + 1u) & 1u) * bm_words;
             ProfScope prof(ctx, "index_append", st);
             index_append_kernel<<<512, 256, 0, st>>>(DS, list, d_lo, d_hi, d_lines.as<IndexLine>(), epoch_idx,
-                                                     d_newbits.as<uint32_t>(), b0, nb, d_touched.as<Deferred>(),
+                                                     map, b0, nb, d_touched.as<Deferred>(),
                                                      dc + C_TOUCH, (uint32_t)max_window_words, dc + C_ERR);
             index_grow_kernel<<<256, 256, 0, st>>>(d_lines.as<IndexLine>(), d_poolp, d_idx.as<uint32_t>(),
                                                    (uint32_t)pool_cap, d_touched.as<Deferred>(), dc + C_TOUCH,
                                                    (uint32_t)max_window_words, dc + C_ERR);
             index_place_kernel<<<256, 256, 0, st>>>(d_lines.as<IndexLine>(), d_poolp, d_touched.as<Deferred>(),
-                                                    dc + C_TOUCH, (uint32_t)max_window_words);
+                                                    dc + C_TOUCH, (uint32_t)max_window_words, reinterpret_cast<uint4 *>(next_map),
+                                                    bm_words / 4);
             LAUNCH_CHECK();
             return PGX_OK;
         };
@@ -2853,6 +2860,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         auto filter_new_and_evaluate = [&](const uint32_t *d_lo, const uint32_t *d_hi) -> int {
             FilterArgs F = FA;
             F.epoch = epoch_idx; F.d_round_lo = d_lo; F.d_round_hi = d_hi;
+            F.newbits = d_newbits.as<uint32_t>() + (size_t)(epoch_idx & 1u) * bm_words;
             {
                 ProfScope prof(ctx, "filter_kernel<new>", st);
                 auto kern = nt ? filter_kernel<true, true> : filter_kernel<false, true>;
@@ -2875,15 +2883,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         static const int n_disc = std::getenv("PGX_ROUNDS") ? std::atoi(std::getenv("PGX_ROUNDS")) : kDiscoveryRounds;
         for (int round = 0; round < n_disc; ++round) {
             if (++epoch_tag == 0xFFFFu) { PGX_HIP(hipMemsetAsync(d_first.p, 0, (size_t)tag_stride * n_codes * 4, st)); epoch_tag = 1; }
-            round_begin_kernel<<<1, 1, 0, st>>>(dc);
-            list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN);
+            const uint32_t which = (uint32_t)round & 1u;
+            uint32_t *const d_n_open = dc + (which ? C_ROUND_OPEN2 : C_ROUND_OPEN);
+            list_open_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_best, d_done, b0, nb, d_ulist.as<uint32_t>(), dc, which);
             LAUNCH_CHECK();
             {
                 ProfScope prof(ctx, "discover_kernels", st);
-                first_open_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
+                first_open_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), d_n_open, b0,
                                                                                  epoch_tag, d_first.as<uint32_t>(), tag_stride,
                                                                                  chunks, d_aan.as<int32_t>(), d_accepted);
-                certain_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), dc + C_ROUND_OPEN, b0,
+                certain_kernel<<<std::min(2048u, (nb + 3) / 4), 256, 0, st>>>(DS, d_ulist.as<uint32_t>(), d_n_open, b0,
                                                                               both ? 1u : 0u, epoch_tag, d_first.as<uint32_t>(), tag_stride,
                                                                               chunks,
                                                                               d_aan.as<int32_t>(), d_accepted, d_done, d_new_list.as<uint32_t>(),
@@ -2907,14 +2916,14 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         for (;;) {
             select_block_kernel<<<1, kSelThreads, 0, st>>>(d_best, d_done, d_inblk, b0, nb, block_cap,
                                                            d_blk_list.as<uint32_t>(), dc + C_BLK, dc + C_NK,
-                                                           d_hascand, window_cap);  // + has_cand, accepted = 0
-            block_begin_kernel<<<1, 1, 0, st>>>(dc);
+                                                           d_hascand, window_cap, dc);  // + has_cand, accepted = 0
             LAUNCH_CHECK();
             {
                 int rc = index_append(d_blk_list.as<uint32_t>(), dc + C_ZERO, dc + C_BLK);
                 if (rc) return rc;
                 FilterArgs F = FA;   // the block's members against the block's (tentative) entries
                 F.epoch = epoch_idx; F.d_round_lo = dc + C_ZERO; F.d_round_hi = dc + C_BLK;
+                F.newbits = d_newbits.as<uint32_t>() + (size_t)(epoch_idx & 1u) * bm_words;
                 F.qlist = d_blk_list.as<uint32_t>(); F.d_nq = dc + C_BLK; F.mark = d_hascand; F.count_visits = 0u;
                 F.pairs = d_pairsK.as<Pair>(); F.n_pairs = dc + C_NK; F.pair_cap = pair_cap_k;
                 F.shard_count = 1; F.shard_index = 0;   // (replicated on every process)
@@ -2977,7 +2986,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 std::copy(h_blk.p, h_blk.p + n_blk, list);
                 n_struck += n_blk;
                 index_strike_kernel<<<std::min(1024u, (n_blk + 3) / 4), 256, 0, st>>>(DS, list, n_blk, d_lines.as<IndexLine>(), d_poolp);
-                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, 0u);
+                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, 0u, nullptr);
                 LAUNCH_CHECK();
                 block_cap = std::max(kBlockCapMin, block_cap / 4);
                 continue;
@@ -3091,8 +3100,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 n_struck += n_out;
                 if (n_out)
                     index_strike_kernel<<<std::min(1024u, (n_out + 3) / 4), 256, 0, st>>>(DS, list, n_out, d_lines.as<IndexLine>(), d_poolp);
-                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, 1u);
-                block_begin_kernel<<<1, 1, 0, st>>>(dc);
+                retire_block_kernel<<<(nb + 255) / 256, 256, 0, st>>>(d_done, d_inblk, nb, 1u, dc);
                 LAUNCH_CHECK();
                 if (overlap && n_open == n_blk) {   // the last block: from here on this window only reads the index
                     PGX_HIP(hipEventRecord(ev.strike[set], st));
