@@ -9,10 +9,10 @@
 //
 // Data layout in HBM
 //   bits[genome][stride] uint64, gene g = bit (g&63) of word (g>>6); stride is a multiple
-//   of 16 words (128 B). A row is cut into 8 equal *stripes* of Ls 16-byte lanes; stripe x
-//   is only ever read by workgroups with blockIdx % 8 == x, i.e. (round-robin dispatch) by
-//   one XCD, so each XCD's private 4 MiB L2 holds 1/8 of the matrix and every re-read of a
-//   row (n_iter times) is an L2 hit instead of an Infinity-Cache / HBM access.
+//   of 16 words (128 B). A row is cut into 8, 4 or 2 equal *stripes* of Ls 16-byte lanes (make_geom);
+//   stripe x is only ever read by workgroups with blockIdx % stripes == x, i.e. (round-robin
+//   dispatch) by one, two or four XCDs, so an XCD's private 4 MiB L2 holds one stripe of every genome
+//   and every re-read of a row (n_iter times) is an L2 hit instead of an Infinity-Cache / HBM access.
 //
 // Work decomposition
 //   item (iter, stripe, v): one wave walks all S steps of iteration `iter` over the lanes
@@ -39,7 +39,7 @@
 
 namespace {
 
-constexpr int PC_STRIPES = 8;  // XCDs per MI355X
+constexpr int PC_XCDS = 8;     // XCDs per MI355X: a row is cut into 8, 4 or 2 stripes, each read by 1, 2 or 4 XCDs only
 constexpr int PC_WAVES = 4;    // waves per workgroup
 constexpr int PC_UNROLL = 8;   // rows in flight per wave
 
@@ -49,18 +49,29 @@ struct PanCoreGeom {
     uint32_t Ls;        // 16-byte lanes per stripe
     uint32_t wps;       // waves per stripe
     uint32_t Lw;        // lanes per wave
-    uint32_t partials;  // 8 * wps
+    uint32_t stripes;   // 8, 4 or 2
+    uint32_t partials;  // stripes * wps
 };
 
-PanCoreGeom make_geom(uint32_t n_genes) {
+// The kernel is bound by vector instructions per wave and step, whatever the number of live lanes: the stripe count is
+// the one that fills the waves best -- 150,000 genes: 8 stripes = 147 lanes = 3 waves of 49 (77 %), 4 stripes = 294 lanes
+// = 5 waves of 59 (92 %: 0.57 -> 0.49 ms per 1000 iterations) -- as long as an XCD's share of the matrix (one stripe of
+// every genome) stays well inside its 4 MiB L2.
+PanCoreGeom make_geom(uint32_t n_genes, uint32_t n_genomes) {
     PanCoreGeom g;
     g.words = (n_genes + 63) / 64;
     g.stride = pgx_bitmap_stride_words(n_genes);
-    g.Ls = g.stride / 16;
-    const uint32_t w0 = (g.Ls + 63) / 64;
-    g.Lw = (g.Ls + w0 - 1) / w0;           // balanced lanes per wave, <= 64
-    g.wps = (g.Ls + g.Lw - 1) / g.Lw;      // so that (wps-1)*Lw < Ls: no empty wave
-    g.partials = PC_STRIPES * g.wps;
+    double best_fill = -1.0;
+    for (uint32_t stripes = PC_XCDS; stripes >= 2; stripes /= 2) {
+        const uint32_t Ls = g.stride / (2 * stripes);                  // (stride is a multiple of 16 words = 8 lanes)
+        if (stripes < PC_XCDS && (uint64_t)n_genomes * Ls * 16 > (3ull << 20)) break;
+        const uint32_t w0 = (Ls + 63) / 64;
+        const uint32_t Lw = (Ls + w0 - 1) / w0;        // balanced lanes per wave, <= 64
+        const uint32_t wps = (Ls + Lw - 1) / Lw;       // so that (wps-1)*Lw < Ls: no empty wave
+        const double fill = (double)Ls / (64.0 * wps);
+        if (fill > best_fill + 0.04) { best_fill = fill; g.stripes = stripes; g.Ls = Ls; g.Lw = Lw; g.wps = wps; }
+    }
+    g.partials = g.stripes * g.wps;
     return g;
 }
 
@@ -70,12 +81,12 @@ __device__ __forceinline__ uint32_t popc128(const uint4 &v) {
 
 __global__ __launch_bounds__(PC_WAVES * 64) void pan_core_sweep_kernel(
     const uint4 *__restrict__ bits, uint32_t stride_bytes, const int32_t *__restrict__ perms,
-    uint32_t n_iter, uint32_t S, uint32_t Ls, uint32_t wps, uint32_t Lw,
+    uint32_t n_iter, uint32_t S, uint32_t Ls, uint32_t wps, uint32_t Lw, uint32_t stripes,
     uint32_t *__restrict__ partial) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t stripe = blockIdx.x & (PC_STRIPES - 1);
+    const uint32_t stripe = blockIdx.x & (stripes - 1);      // (block b runs on XCD b % 8: stripe x stays with XCDs x, x + stripes, ...)
     const uint32_t item = __builtin_amdgcn_readfirstlane(
-        (blockIdx.x / PC_STRIPES) * PC_WAVES + (threadIdx.x >> 6));
+        (blockIdx.x / stripes) * PC_WAVES + (threadIdx.x >> 6));
     if (item >= n_iter * wps) return;  // wave-uniform
     const uint32_t iter = item / wps;
     const uint32_t v = item - iter * wps;
@@ -268,7 +279,7 @@ uint32_t pgx_bitmap_stride_words(uint32_t n_genes) {
 }
 
 size_t pgx_pan_core_workspace_bytes(uint32_t n_genes, uint32_t n_genomes, uint32_t n_iter) {
-    const PanCoreGeom g = make_geom(n_genes);
+    const PanCoreGeom g = make_geom(n_genes, n_genomes);
     return (size_t)g.partials * n_iter * n_genomes * sizeof(uint32_t);
 }
 
@@ -341,15 +352,15 @@ int pgx_pan_core_dev(pgx_ctx *ctx, const uint64_t *d_bits, uint32_t n_genes, uin
                 "workspace too small (see pgx_pan_core_workspace_bytes)");
     PGX_REQUIRE(((uintptr_t)d_bits & 15u) == 0, "bitmap must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
-    const PanCoreGeom g = make_geom(n_genes);
+    const PanCoreGeom g = make_geom(n_genes, n_genomes);
     const uint32_t n_partials = g.partials;
     {
         const uint64_t items = (uint64_t)n_iter * g.wps;  // per stripe
-        const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * PC_STRIPES;
+        const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * g.stripes;
         PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
         ProfScope prof(ctx, "pan_core_sweep_kernel", stream);
         pan_core_sweep_kernel<<<(uint32_t)blocks, PC_WAVES * 64, 0, stream>>>(
-            (const uint4 *)d_bits, g.stride * 8, d_perms, n_iter, n_genomes, g.Ls, g.wps, g.Lw,
+            (const uint4 *)d_bits, g.stride * 8, d_perms, n_iter, n_genomes, g.Ls, g.wps, g.Lw, g.stripes,
             (uint32_t *)d_workspace);
     }
     PGX_HIP(hipGetLastError());
@@ -506,14 +517,14 @@ int pgx_pan_core_table(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes
         PGX_HIP(d_ws.alloc(nws));
         PGX_HIP(d_table.alloc(nperm * 4));
         PGX_HIP(hipMemcpyAsync(d_perms.p, out_perms, nperm, hipMemcpyHostToDevice, ctx->stream));
-        const PanCoreGeom g = make_geom(n_genes);
+        const PanCoreGeom g = make_geom(n_genes, n_genomes);
         {
             const uint64_t items = (uint64_t)n_iter * g.wps;  // per stripe
-            const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * PC_STRIPES;
+            const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * g.stripes;
             PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
             ProfScope prof(ctx, "pan_core_sweep_kernel", ctx->stream);
             pan_core_sweep_kernel<<<(uint32_t)blocks, PC_WAVES * 64, 0, ctx->stream>>>(
-                d_bits.as<uint4>(), g.stride * 8, d_perms.as<int32_t>(), n_iter, n_genomes, g.Ls, g.wps, g.Lw,
+                d_bits.as<uint4>(), g.stride * 8, d_perms.as<int32_t>(), n_iter, n_genomes, g.Ls, g.wps, g.Lw, g.stripes,
                 d_ws.as<uint32_t>());
         }
         PGX_HIP(hipGetLastError());
