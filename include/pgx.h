@@ -324,6 +324,21 @@ int pgx_pan_core_table(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes
                        uint32_t n_iter, int32_t *out_perms, double *out_table, uint64_t *out_duplicates,
                        uint64_t *out_not_one);
 
+/* Device-resident hand-off (SURVEY build plan step 5; north_star "emitting the gene x genome presence/absence bitmap"):
+ * the bitmap of a pangenome is built ON THE DEVICE straight from the clustering result -- record r of the genome files is
+ * an instance of gene cluster_of_group[group_of_record[r]] in genome genome_of_file[file_of_record[r]] (negative group or
+ * cluster: nothing), rows = cluster numbers -- and stays in the context until the next pgx_bitmap_from_clusters on it.
+ * out_token names it; pgx_pan_core_table_resident computes estimate_pan_core_size()'s table from it with no upload of
+ * the table at all (the curves do not depend on the order of the rows); pgx_bitmap_resident_read copies it out
+ * (n_genomes x pgx_bitmap_stride_words(n_genes) words). A stale token fails with PGX_ERR_INVALID. */
+int pgx_bitmap_from_clusters(pgx_ctx *ctx, const int32_t *cluster_of_group, uint64_t n_groups,
+                             const int32_t *group_of_record, const uint32_t *file_of_record, uint64_t n_records,
+                             const int32_t *genome_of_file, uint32_t n_files, uint32_t n_genes, uint32_t n_genomes,
+                             uint64_t *out_token);
+int pgx_bitmap_resident_read(pgx_ctx *ctx, uint64_t token, uint64_t *out_bits);
+int pgx_pan_core_table_resident(pgx_ctx *ctx, uint64_t token, uint32_t n_genes, uint32_t n_genomes, uint32_t *mt_key,
+                                int32_t *mt_pos, uint32_t n_iter, int32_t *out_perms, double *out_table);
+
 /* feature names (pangenome.py:1944-1969) as fixed-width zero-padded ASCII records (numpy 'S<width>'):
  * <prefix><cluster>[<variant><member>]; variant NULL = gene names */
 int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,

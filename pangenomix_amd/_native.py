@@ -84,6 +84,10 @@ SIGNATURES = {
                                       _P, _P, _P, C.POINTER(C.c_uint64)]),
     'pgx_pan_core_table': (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_int32), C.c_uint32,
                                     _P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    'pgx_bitmap_from_clusters': (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.POINTER(C.c_uint64)]),
+    'pgx_bitmap_resident_read': (C.c_int, [_P, C.c_uint64, _P]),
+    'pgx_pan_core_table_resident': (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_int32), C.c_uint32, _P, _P]),
     'pgx_format_labels': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_format_labels_ucs4': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_fasta_write_clustered': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _S, _S, _S, _S, _S]),
@@ -329,6 +333,35 @@ class Context(object):
                                        int(n_genomes), _ptr(mt_key), C.byref(pos), int(n_iter), _ptr(perms), _ptr(table),
                                        C.byref(dup), C.byref(bad)))
         return table, int(dup.value), int(bad.value), perms, int(pos.value)
+
+    # -- device-resident hand-off: clustering result -> bitmap kept in the context -> pan/core curves --------------
+    def bitmap_from_clusters(self, cluster_of_group, group_of_record, file_of_record, genome_of_file, n_genes, n_genomes):
+        """Build the gene x genome bitmap on the device from a clustering result and keep it there; returns its token
+        (pgx.h: pgx_bitmap_from_clusters)."""
+        cl = np.ascontiguousarray(cluster_of_group, dtype=np.int32)
+        grp = np.ascontiguousarray(group_of_record, dtype=np.int32)
+        fil = np.ascontiguousarray(file_of_record, dtype=np.uint32)
+        gof = np.ascontiguousarray(genome_of_file, dtype=np.int32)
+        if grp.shape != fil.shape:
+            raise ValueError('group_of_record and file_of_record must have one entry per record')
+        token = C.c_uint64(0)
+        check(lib().pgx_bitmap_from_clusters(self._h, _ptr(cl), cl.size, _ptr(grp), _ptr(fil), grp.size, _ptr(gof), gof.size,
+                                             int(n_genes), int(n_genomes), C.byref(token)))
+        return int(token.value)
+
+    def bitmap_resident_read(self, token, n_genes, n_genomes):
+        bits = np.empty((int(n_genomes), lib().pgx_bitmap_stride_words(int(n_genes))), dtype=np.uint64)
+        check(lib().pgx_bitmap_resident_read(self._h, int(token), _ptr(bits)))
+        return bits
+
+    def pan_core_table_resident(self, token, n_genes, n_genomes, n_iter, mt_key, mt_pos):
+        """(table float64 [n_iter, 2 n_genomes], perms, new_pos) from the bitmap that is resident under `token`."""
+        perms = np.empty((int(n_iter), int(n_genomes)), dtype=np.int32)
+        table = np.empty((int(n_iter), 2 * int(n_genomes)), dtype=np.float64)
+        pos = C.c_int32(int(mt_pos))
+        check(lib().pgx_pan_core_table_resident(self._h, int(token), int(n_genes), int(n_genomes), _ptr(mt_key), C.byref(pos),
+                                                int(n_iter), _ptr(perms), _ptr(table)))
+        return table, perms, int(pos.value)
 
     def pan_core(self, bits, n_genes, perms):
         perms = np.ascontiguousarray(perms, dtype=np.int32)

@@ -199,6 +199,35 @@ __global__ __launch_bounds__(256) void pan_core_reduce_kernel(const uint32_t *__
     }
 }
 
+// The gene x genome bitmap straight from a clustering result: record r of the genome files is an instance of gene
+// cluster_of_group[group_of_record[r]] in genome genome_of_file[file_of_record[r]] (records without a sequence or
+// outside every cluster set nothing). What build_genetic_feature_tables (pangenome.py:563-680) derives per record.
+__global__ __launch_bounds__(256) void bitmap_from_clusters_kernel(const int32_t *__restrict__ cluster_of_group,
+                                                                  uint32_t n_groups,
+                                                                  const int32_t *__restrict__ group_of_record,
+                                                                  const uint32_t *__restrict__ file_of_record,
+                                                                  uint64_t n_records,
+                                                                  const int32_t *__restrict__ genome_of_file,
+                                                                  uint32_t n_files, uint32_t n_genes, uint32_t n_genomes,
+                                                                  uint32_t stride, unsigned long long *__restrict__ bits,
+                                                                  unsigned long long *__restrict__ counters) {
+    uint32_t bad = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_records; r += (uint64_t)gridDim.x * blockDim.x) {
+        const int32_t g = group_of_record[r];
+        if (g < 0) continue;
+        const uint32_t f = file_of_record[r];
+        if ((uint32_t)g >= n_groups || f >= n_files) { ++bad; continue; }
+        const int32_t gene = cluster_of_group[g], genome = genome_of_file[f];
+        if (gene < 0) continue;
+        if ((uint32_t)gene >= n_genes || (uint32_t)genome >= n_genomes) { ++bad; continue; }
+        const unsigned long long bit = 1ull << ((uint32_t)gene & 63u);
+        unsigned long long *w = &bits[(size_t)genome * stride + ((uint32_t)gene >> 6)];
+        if (!(*w & bit)) atomicOr(w, bit);
+    }
+    for (int d = 32; d > 0; d >>= 1) bad += __shfl_xor(bad, d);
+    if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(&counters[1], (unsigned long long)bad);
+}
+
 // The same sum written as the table estimate_pan_core_size() returns: float64 [n_iter][2 S], pan curves in columns
 // 0..S-1, core curves in S..2S-1 (pangenome_analysis.py:93-97) -- the int -> float conversion and the side-by-side
 // layout cost the host 1-2 ms per call (np.hstack + astype) and nothing here.
@@ -263,7 +292,7 @@ __global__ __launch_bounds__(256) void row_counts_kernel(const unsigned long lon
 
 // K3 device buffers of the host-pointer entry points live in the context's grow-only workspace
 // (slots after the clustering's), so repeated calls neither allocate nor free.
-enum { PC_SLOT_ROWS = 80, PC_SLOT_GENOMES, PC_SLOT_BITS, PC_SLOT_PERMS, PC_SLOT_PAN, PC_SLOT_CORE, PC_SLOT_WS, PC_SLOT_CNT, PC_SLOT_COUNTS, PC_SLOT_TABLE };
+enum { PC_SLOT_ROWS = 80, PC_SLOT_GENOMES, PC_SLOT_BITS, PC_SLOT_PERMS, PC_SLOT_PAN, PC_SLOT_CORE, PC_SLOT_WS, PC_SLOT_CNT, PC_SLOT_COUNTS, PC_SLOT_TABLE, PC_SLOT_RESIDENT, PC_SLOT_RES_A, PC_SLOT_RES_B, PC_SLOT_RES_C, PC_SLOT_RES_D };
 struct PcBuf : DevBuf {
     PcBuf(pgx_ctx *c, int s) { ctx = c; slot = s; }
 };
@@ -542,6 +571,106 @@ int pgx_pan_core_table(pgx_ctx *ctx, const int32_t *rows, const int32_t *genomes
     PGX_HIP(hipStreamSynchronize(ctx->stream));
     PGX_REQUIRE(cnt[1] == 0, "record with row or genome index out of range");
     if (out_duplicates) *out_duplicates = cnt[0];
+    return PGX_OK;
+}
+
+// ---- device-resident hand-off: clustering result -> bitmap (kept in the context) -> pan/core curves ---------------
+int pgx_bitmap_from_clusters(pgx_ctx *ctx, const int32_t *cluster_of_group, uint64_t n_groups,
+                             const int32_t *group_of_record, const uint32_t *file_of_record, uint64_t n_records,
+                             const int32_t *genome_of_file, uint32_t n_files, uint32_t n_genes, uint32_t n_genomes,
+                             uint64_t *out_token) {
+    PGX_REQUIRE(ctx && out_token, "NULL argument");
+    PGX_REQUIRE(n_records == 0 || (cluster_of_group && group_of_record && file_of_record && genome_of_file), "NULL arrays");
+    PGX_REQUIRE(n_groups < (1ull << 31), "too many groups");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    *out_token = 0;
+    ctx->resident_token = 0;                         // (whatever was resident is gone from here on)
+    const uint32_t stride = pgx_bitmap_stride_words(n_genes);
+    const size_t nbits = (size_t)n_genomes * stride * 8;
+    PcBuf d_bits(ctx, PC_SLOT_RESIDENT), d_cl(ctx, PC_SLOT_RES_A), d_grp(ctx, PC_SLOT_RES_B), d_file(ctx, PC_SLOT_RES_C),
+        d_gof(ctx, PC_SLOT_RES_D), d_cnt(ctx, PC_SLOT_CNT);
+    PGX_HIP(d_bits.alloc(nbits));
+    PGX_HIP(d_cl.alloc(n_groups * 4));
+    PGX_HIP(d_grp.alloc(n_records * 4));
+    PGX_HIP(d_file.alloc(n_records * 4));
+    PGX_HIP(d_gof.alloc((size_t)n_files * 4));
+    PGX_HIP(d_cnt.alloc(16));
+    hipStream_t st = ctx->stream;
+    PGX_HIP(hipMemsetAsync(d_bits.p, 0, nbits, st));
+    PGX_HIP(hipMemsetAsync(d_cnt.p, 0, 16, st));
+    if (n_records) {
+        int rc = pgx_staged_h2d(ctx, d_cl.p, cluster_of_group, n_groups * 4, st);
+        if (rc == PGX_OK) rc = pgx_staged_h2d(ctx, d_grp.p, group_of_record, n_records * 4, st);
+        if (rc == PGX_OK) rc = pgx_staged_h2d(ctx, d_file.p, file_of_record, n_records * 4, st);
+        if (rc != PGX_OK) return rc;
+        PGX_HIP(hipMemcpyAsync(d_gof.p, genome_of_file, (size_t)n_files * 4, hipMemcpyHostToDevice, st));
+        const uint64_t want = (n_records + 255) / 256;
+        ProfScope prof(ctx, "presence_bitmap_kernel", st);
+        bitmap_from_clusters_kernel<<<(uint32_t)(want < 4096 ? want : 4096), 256, 0, st>>>(
+            d_cl.as<int32_t>(), (uint32_t)n_groups, d_grp.as<int32_t>(), d_file.as<uint32_t>(), n_records, d_gof.as<int32_t>(),
+            n_files, n_genes, n_genomes, stride, d_bits.as<unsigned long long>(), d_cnt.as<unsigned long long>());
+        PGX_HIP(hipGetLastError());
+    }
+    uint64_t cnt[2] = {0, 0};
+    PGX_HIP(hipMemcpyAsync(cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, st));
+    PGX_HIP(hipStreamSynchronize(st));
+    PGX_REQUIRE(cnt[1] == 0, "group, file, gene or genome index out of range");
+    ctx->resident_token = ctx->resident_next++;
+    ctx->resident_genes = n_genes; ctx->resident_genomes = n_genomes;
+    *out_token = ctx->resident_token;
+    return PGX_OK;
+}
+
+int pgx_bitmap_resident_read(pgx_ctx *ctx, uint64_t token, uint64_t *out_bits) {
+    PGX_REQUIRE(ctx && out_bits, "NULL argument");
+    PGX_REQUIRE(token != 0 && token == ctx->resident_token, "the bitmap of that token is not resident any more");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    PcBuf d_bits(ctx, PC_SLOT_RESIDENT);
+    const size_t nbits = (size_t)ctx->resident_genomes * pgx_bitmap_stride_words(ctx->resident_genes) * 8;
+    PGX_HIP(d_bits.alloc(nbits));                     // (a view of the slot: no allocation)
+    PGX_HIP(hipMemcpyAsync(out_bits, d_bits.p, nbits, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipStreamSynchronize(ctx->stream));
+    return PGX_OK;
+}
+
+int pgx_pan_core_table_resident(pgx_ctx *ctx, uint64_t token, uint32_t n_genes, uint32_t n_genomes, uint32_t *mt_key,
+                                int32_t *mt_pos, uint32_t n_iter, int32_t *out_perms, double *out_table) {
+    PGX_REQUIRE(ctx && mt_key && mt_pos, "NULL argument");
+    PGX_REQUIRE(token != 0 && token == ctx->resident_token && n_genes == ctx->resident_genes && n_genomes == ctx->resident_genomes,
+                "the bitmap of that token is not resident any more");
+    PGX_REQUIRE(n_iter == 0 || n_genomes == 0 || (out_perms && out_table), "NULL argument");
+    PGX_HIP(hipSetDevice(ctx->device_id));
+    int rc = pgx_legacy_shuffles(mt_key, mt_pos, n_genomes, n_iter, out_perms);
+    if (rc != PGX_OK) return rc;
+    if (n_iter == 0 || n_genomes == 0) return PGX_OK;
+    const size_t nperm = (size_t)n_iter * n_genomes * 4;
+    const size_t nws = pgx_pan_core_workspace_bytes(n_genes, n_genomes, n_iter);
+    PcBuf d_bits(ctx, PC_SLOT_RESIDENT), d_perms(ctx, PC_SLOT_PERMS), d_ws(ctx, PC_SLOT_WS), d_table(ctx, PC_SLOT_TABLE);
+    PGX_HIP(d_bits.alloc((size_t)n_genomes * pgx_bitmap_stride_words(n_genes) * 8));   // (a view of the slot)
+    PGX_HIP(d_perms.alloc(nperm));
+    PGX_HIP(d_ws.alloc(nws));
+    PGX_HIP(d_table.alloc(nperm * 4));
+    PGX_HIP(hipMemcpyAsync(d_perms.p, out_perms, nperm, hipMemcpyHostToDevice, ctx->stream));
+    const PanCoreGeom g = make_geom(n_genes, n_genomes);
+    {
+        const uint64_t items = (uint64_t)n_iter * g.wps;
+        const uint64_t blocks = ((items + PC_WAVES - 1) / PC_WAVES) * g.stripes;
+        PGX_REQUIRE(blocks < (1ull << 31), "problem too large for one launch");
+        ProfScope prof(ctx, "pan_core_sweep_kernel", ctx->stream);
+        pan_core_sweep_kernel<<<(uint32_t)blocks, PC_WAVES * 64, 0, ctx->stream>>>(
+            d_bits.as<uint4>(), g.stride * 8, d_perms.as<int32_t>(), n_iter, n_genomes, g.Ls, g.wps, g.Lw, g.stripes,
+            d_ws.as<uint32_t>());
+    }
+    PGX_HIP(hipGetLastError());
+    {
+        const size_t want = ((size_t)n_iter * n_genomes + 255) / 256;
+        ProfScope prof(ctx, "pan_core_reduce_kernel", ctx->stream);
+        pan_core_reduce_table_kernel<<<(uint32_t)(want < 2048 ? want : 2048), 256, 0, ctx->stream>>>(
+            d_ws.as<uint32_t>(), g.partials, n_iter, n_genomes, d_table.as<double>());
+    }
+    PGX_HIP(hipGetLastError());
+    PGX_HIP(hipMemcpyAsync(out_table, d_table.p, nperm * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PGX_HIP(hipStreamSynchronize(ctx->stream));
     return PGX_OK;
 }
 

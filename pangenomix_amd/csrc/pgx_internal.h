@@ -40,6 +40,9 @@ struct pgx_ctx {
     // and from the device are asynchronous (from pageable memory every hipMemcpyAsync blocked the host)
     std::vector<std::pair<void *, size_t>> host_scratch;
     std::vector<hipEvent_t> stage_events;   // pgx_staged_h2d: one per staging buffer (its last DMA)
+    // the gene x genome bitmap a pipeline left on the device (pgx_bitmap_from_clusters): its token, shape, buffer
+    uint64_t resident_token = 0, resident_next = 1;
+    uint32_t resident_genes = 0, resident_genomes = 0;
 };
 
 // Array of n elements of T in the context's host scratch slot `slot` (uninitialised unless `fill` is given).

@@ -519,6 +519,20 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         out = (sparse_utils.LightSparseDataFrame(allele_order, genome_order, sp_alleles),
                sparse_utils.LightSparseDataFrame(gene_order, genome_order, sp_genes))
         lap('tables')
+        if cluster_fn is None:
+            # Device-resident hand-off: the gene x genome bitmap is built on the GPU straight from the clustering
+            # result (rows = cluster numbers; the curves do not depend on the row order) and stays in the context;
+            # estimate_pan_core_size(df_genes) on the returned table uses it instead of uploading the table's
+            # coordinates, as long as the table is the object returned here and the bitmap is still resident.
+            try:
+                ctx = _native.default_context()
+                token = ctx.bitmap_from_clusters(cl, fs.group_of_record, fs.file_of_record, genome_of_file,
+                                                 len(gene_order), len(genome_order))
+                out[1]._pgx_resident = {'ctx': ctx, 'token': token, 'shape': out[1].shape, 'data': out[1].data,
+                                        'nnz': int(out[1].data.nnz)}
+            except _native.PgxError as exc:       # (the tables are complete without it)
+                print('Note: no device-resident bitmap (%s)' % exc)
+            lap('device-resident bitmap')
         return out
     finally:
         fs.close()

@@ -117,3 +117,43 @@ def test_full_size_properties(gpu_ctx):
     # identical permutations give identical rows; reversing a permutation keeps the end points
     pan2, core2 = gpu_ctx.pan_core(bits, G, perms[::-1].copy())
     assert np.array_equal(pan2[::-1], pan) and np.array_equal(core2[::-1], core)
+
+
+def test_device_resident_handoff_from_the_pipeline(tmp_path, gpu_ctx):
+    """SURVEY build plan step 5: build_cds_pangenome() leaves the gene x genome bitmap ON THE DEVICE, built there from the
+    clustering result (rows = cluster numbers), and estimate_pan_core_size(df_genes) on the returned table consumes it
+    without uploading the table: same curves, same generator state as the path that uploads the coordinates; the bitmap
+    equals the one built from the table's own coordinates; a later pipeline makes the token stale and the call falls back."""
+    import copy
+    from pangenomix_amd import _native, pangenome, sparse_utils, synth
+    from pangenomix_amd import pangenome_analysis as pa
+    ctx = _native.default_context()
+    paths = synth.ProteinSet(9, 300, 400, 90, 5).write_faa(str(tmp_path / 'g1'))
+    (tmp_path / 'o1').mkdir()
+    dfa, dfg = pangenome.build_cds_pangenome(paths, str(tmp_path / 'o1'), name='R')
+    res = dfg._pgx_resident
+    assert res['token'] and res['shape'] == dfg.shape
+    # the resident bitmap against the table's own coordinates (row = cluster number of the gene name)
+    G, S = dfg.shape
+    cluster_of_row = np.array([int(str(x).rsplit('_C', 1)[1]) for x in dfg.index], dtype=np.int32)
+    coo = dfg.data.tocoo()
+    want_bits, dup = ctx.presence_bitmap(cluster_of_row[coo.row], coo.col.astype(np.int32), G, S, return_duplicates=True)
+    assert dup == 0 and np.array_equal(ctx.bitmap_resident_read(res['token'], G, S), want_bits)
+    plain = sparse_utils.LightSparseDataFrame(list(dfg.index), list(dfg.columns), dfg.data.copy())   # no hand-off
+    np.random.seed(3)
+    a = pa.estimate_pan_core_size(dfg, 50)
+    state_a = np.random.get_state()
+    np.random.seed(3)
+    b = pa.estimate_pan_core_size(plain, 50)
+    state_b = np.random.get_state()
+    assert a.equals(b) and state_a[2] == state_b[2] and np.array_equal(state_a[1], state_b[1])
+    assert a.values[:, S - 1].max() == G                      # all genomes: every gene
+    # another pipeline replaces the resident bitmap: the first table's token is stale, its call uploads instead
+    paths2 = synth.ProteinSet(5, 200, 300, 60, 6).write_faa(str(tmp_path / 'g2'))
+    (tmp_path / 'o2').mkdir()
+    pangenome.build_cds_pangenome(paths2, str(tmp_path / 'o2'), name='R2')
+    with pytest.raises(_native.PgxError):
+        ctx.bitmap_resident_read(res['token'], G, S)
+    np.random.seed(3)
+    c = pa.estimate_pan_core_size(dfg, 50)
+    assert c.equals(b)
