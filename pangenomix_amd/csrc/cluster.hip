@@ -165,14 +165,26 @@ __device__ __forceinline__ bool is_letter(uint8_t ch) {
 
 // one wave per input sequence
 __global__ __launch_bounds__(256) void seq_len_kernel(const uint8_t *__restrict__ res,
-                                                     const uint64_t *__restrict__ off, uint32_t n,
+                                                     const uint64_t *__restrict__ off, uint32_t n, uint64_t total,
                                                      uint32_t *__restrict__ len) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (i >= n) return;
     const uint64_t b = off[i], e = off[i + 1];
     uint32_t c = 0;
-    for (uint64_t p = b + lane; p < e; p += 64) c += is_letter(res[p]);
+    // four bytes per lane and load (a byte per lane moves 64 bytes per load instruction: the kernel was bound by their
+    // number): aligned words from the word that holds byte b on, bytes outside [b, e) masked out
+    const uint64_t a0 = b & ~3ull;
+    for (uint64_t a = a0 + 4ull * lane; a < e; a += 256) {
+        uint32_t word = 0;
+        if (a + 4 <= total) word = *reinterpret_cast<const uint32_t *>(res + a);
+        else for (uint64_t p = a; p < total; ++p) word |= (uint32_t)res[p] << (8 * (p - a));   // (the buffer's last bytes)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint64_t p = a + t;
+            c += (p >= b && p < e) && is_letter((uint8_t)(word >> (8 * t)));
+        }
+    }
     for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
     if (lane == 0) len[i] = c;
 }
@@ -190,18 +202,23 @@ __global__ __launch_bounds__(256) void encode_gather_kernel(const uint8_t *__res
     const uint32_t src = order[k];
     const uint64_t b = in_off[src], e = in_off[src + 1];
     uint64_t w = out_off[k];
-    for (uint64_t p0 = b; p0 < e; p0 += 64) {
-        const uint64_t p = p0 + lane;
-        const uint8_t ch = p < e ? in[p] : 0;
-        const bool ok = is_letter(ch);
-        const unsigned long long m = __ballot(ok);
-        if (ok) {
-            const uint8_t up = ch & 0xDF;
-            const uint8_t idx = nt ? (uint8_t)(up == 'A' ? 0 : up == 'C' ? 1 : up == 'G' ? 2 : (up == 'T' || up == 'U') ? 3 : 4)
-                                   : (uint8_t)kAa2Idx_dev[up - 'A'];
-            out[w + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+    for (uint64_t q0 = b; q0 < e; q0 += 256) {           // (four slabs of 64 bytes loaded before any is compacted)
+        uint8_t chs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint64_t p = q0 + 64u * j + lane; chs[j] = p < e ? in[p] : (uint8_t)0; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint8_t ch = chs[j];
+            const bool ok = is_letter(ch);
+            const unsigned long long m = __ballot(ok);
+            if (ok) {
+                const uint8_t up = ch & 0xDF;
+                const uint8_t idx = nt ? (uint8_t)(up == 'A' ? 0 : up == 'C' ? 1 : up == 'G' ? 2 : (up == 'T' || up == 'U') ? 3 : 4)
+                                       : (uint8_t)kAa2Idx_dev[up - 'A'];
+                out[w + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+            }
+            w += __popcll(m);
         }
-        w += __popcll(m);
     }
 }
 
@@ -2258,7 +2275,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_HIP(d_in_len.alloc((size_t)n_in * 4));
     {
         ProfScope prof(ctx, "seq_len_kernel", st);
-        seq_len_kernel<<<(n_in + 3) / 4, 256, 0, st>>>(d_residues, d_offsets, n_in, d_in_len.as<uint32_t>());
+        seq_len_kernel<<<(n_in + 3) / 4, 256, 0, st>>>(d_residues, d_offsets, n_in, total_in, d_in_len.as<uint32_t>());
     }
     LAUNCH_CHECK();
     // (the per-sequence host arrays live in the context's scratch: no allocation, page faults or frees per call)
