@@ -258,6 +258,23 @@ __global__ __launch_bounds__(256) void pack5_kernel(const uint8_t *__restrict__ 
 // ----------------------------------------------------------------------------------------
 // words: encode all k-mers of a sequence, sort them in LDS (bitonic), collapse runs
 // ----------------------------------------------------------------------------------------
+// exclusive prefix of `v` over the workgroup's threads (and the total): a shuffle scan inside every wave, the waves'
+// totals through LDS -- one barrier instead of the fourteen of a Hillis-Steele scan over 128 threads in LDS
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *__restrict__ wave_tot /* LDS, THREADS / 64 + 1 */,
+                                                    uint32_t *total) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t x = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+    if (lane == 63u) wave_tot[wave] = x;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) { const uint32_t t = wave_tot[w]; before += (uint32_t)w < wave ? t : 0u; all += t; }
+    *total = all;
+    return before + x - v;
+}
+
 template <int NCAP, int THREADS>
 __global__ __launch_bounds__(THREADS) void words_kernel(const uint8_t *__restrict__ res,
                                                         const uint64_t *__restrict__ off,
@@ -371,16 +388,9 @@ __global__ __launch_bounds__(THREADS) void words_hash_kernel(const uint8_t *__re
     const uint32_t beg = tid * C;
     uint32_t mine = 0;
     for (uint32_t i = beg; i < beg + C; ++i) mine += hk[i] != kSentinel;
-    part[tid] = mine;
-    __syncthreads();
-    for (uint32_t d = 1; d < THREADS; d <<= 1) {          // inclusive Hillis-Steele scan
-        const uint32_t v = tid >= d ? part[tid - d] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t idx = part[tid] - mine;
-    if (tid == THREADS - 1) wcnt[k] = part[tid];
+    uint32_t total;
+    uint32_t idx = block_excl_scan<THREADS>(mine, part, &total);
+    if (tid == 0) wcnt[k] = total;
     for (uint32_t i = beg; i < beg + C; ++i)
         if (hk[i] != kSentinel) { wcode[o + idx] = hk[i]; wmult[o + idx] = (uint16_t)hc[i]; ++idx; }
 }
