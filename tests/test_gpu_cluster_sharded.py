@@ -201,3 +201,37 @@ def test_overlapped_windows_under_exchange_match_the_serial_loop(monkeypatch):
     serial = run_virtual_ranks(res, off, p, 2)
     assert_same(fold(both), fold(serial))
     assert_same(fold(both), oracle.cluster_greedy(res, off, p))
+
+
+def test_edge_cases_on_virtual_ranks():
+    """What a record-sharded call must survive without leaving a rank behind: nothing to cluster, fewer sequences than
+    ranks, nucleotide rules with flush positions, a giant sequence."""
+    from test_cluster_oracle import pack, rand_seq, mutate, rand_nt
+    rng = np.random.default_rng(91)
+    # nothing to cluster / everything too short
+    for seqs in ([], ['MKV', 'ACD']):
+        res, off = pack(seqs)
+        results = run_virtual_ranks(res, off, params(), 2)
+        assert all(r[4] == 0 for r in results) and all((r[0] < 0).all() for r in results)
+    # fewer sequences than ranks
+    a = rand_seq(rng, 120)
+    res, off = pack([a, mutate(rng, a, 5)])
+    results = run_virtual_ranks(res, off, params(), 3)
+    assert_replicated(results)
+    assert_same(fold(results), oracle.cluster_greedy(res, off, params()))
+    # nucleotide rules, both strands, with flush positions
+    res, off, _ = synth.noncoding_set(n_genomes=40, seed=11)
+    p = nt_params()
+    n = oracle.cluster_greedy(res, off, p)[5]['n_clustered']
+    pc, keep = cluster.with_chunk_boundaries(p, [n // 3, n // 2])
+    results = run_virtual_ranks(res, off, pc, 2)
+    assert_replicated(results)
+    assert_same_nt(fold(results), oracle.cluster_greedy(res, off, pc))
+    # a giant protein and its variant among ordinary sequences
+    g = rand_seq(rng, 34000)
+    seqs = [g, mutate(rng, g, 900)] + [rand_seq(rng, 250) for _ in range(20)]
+    seqs += [mutate(rng, s_, 8) for s_ in seqs[2:12]]
+    res, off = pack(seqs)
+    results = run_virtual_ranks(res, off, params(), 2)
+    assert_replicated(results)
+    assert_same(fold(results), oracle.cluster_greedy(res, off, params()))
