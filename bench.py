@@ -144,6 +144,9 @@ def main():
     ap.add_argument('--shard', choices=['records', 'replicas'], default='records',
                     help='N > 1: ONE clustering job sharded by record over the ranks (default, strong scaling) or N '
                          'independent replicas (weak scaling)')
+    ap.add_argument('--exchange', choices=['torch', 'native'], default='torch',
+                    help='the all-gather of the record-sharded mode: torch.distributed (nccl backend) through the '
+                         'callback, or the library\'s own ncclAllGather (pgx_rccl_*); RCCL over xGMI either way')
     ap.add_argument('--only', choices=['all', 'cluster', 'pancore'], default='all',
                     help='restrict the step (used for rocprofv3 counter passes); the JSON line needs all')
     args = ap.parse_args()
@@ -200,8 +203,12 @@ def main():
     n_nr = off.size - 1
     params = base_params = cluster.params_from_cdhit_args({'-n': 5, '-c': 0.8})
     if sharded:   # every rank holds the same sequences; window member i belongs to rank i % world
-        send, recv = cluster.exchange_buffers(world, dev)
-        params, _keep = cluster.shard_params(params, rank, world, send, recv, cluster.group_all_gather(dist.group.WORLD))
+        if args.exchange == 'native':
+            cluster.native_comm(ctx, dist.group.WORLD)
+            params = cluster.native_shard_params(params, rank, world)
+        else:
+            send, recv = cluster.exchange_buffers(world, dev)
+            params, _keep = cluster.shard_params(params, rank, world, send, recv, cluster.group_all_gather(dist.group.WORLD))
     d_res = torch.from_numpy(res.copy()).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     S = 400
@@ -535,7 +542,9 @@ def main():
                                    'on synthetic %d x %d matrix' % (workload, pset.n_genomes, pset.cds, n_raw,
                                                                     n_nr, n_clusters, n_iter, G, S),
                        'parallelism': ('record-sharded x%d: one job, window member i on rank i %% %d, all-gather of the '
-                                       'best keys per evaluation; pan/core iterations split' % (world, world)) if sharded
+                                       'best keys per evaluation (%s); pan/core iterations split'
+                                       % (world, world, 'ncclAllGather enqueued by libpgx' if args.exchange == 'native'
+                                          else 'torch.distributed, nccl backend')) if sharded
                        else ('replicas x%d' % world if world > 1 else 'one GPU')},
             'pan_core': {'value': jobs * n_iter * steps / t_pancore, 'unit': 'iters/s',
                          'ms': t_pancore / steps * 1e3, 'roofline': extra['roofline_pc'],

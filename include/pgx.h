@@ -186,6 +186,8 @@ typedef struct pgx_cluster_params {
      * xGMI with the nccl backend. Every process issues its calls in the same order. 0 = success. A few calls per
      * window. The word behind the keys carries the process's error state: a capacity failure on one process makes
      * every process return PGX_ERR_CAPACITY at the same point (nobody is left waiting in a collective). */
+    /* (exchange == NULL with shard_count >= 1: the context's own communicator, pgx_rccl_comm_create below; the
+     * exchange_* fields are then unused) */
     int (*exchange)(void *user, void *stream, int slot);
     void *exchange_user;
     void *exchange_send;    /* device (the caller's allocation, so that its collective library can address it) */
@@ -249,6 +251,21 @@ int pgx_cluster_greedy_dev(pgx_ctx *ctx, const uint8_t *d_residues, const uint64
                            uint64_t total_bytes, const pgx_cluster_params *params, int32_t *out_cluster,
                            int32_t *out_member, float *out_identity, uint8_t *out_strand,
                            uint32_t *out_n_clusters, pgx_cluster_stats *stats, void *stream);
+
+/* The record-sharded mode without a callback: the library's own RCCL communicator (optional). With shard_count >= 1,
+ * exchange == NULL and a communicator on the context, pgx_cluster_greedy[_dev] keeps the exchange buffers itself and
+ * enqueues ncclAllGather on the window's stream (RCCL over xGMI; nothing of the host language in the loop).
+ *   pgx_rccl_load         dlopen of librccl.so (path NULL = the loader's search path; a PyTorch-ROCm process passes
+ *                         torch/lib/librccl.so so that the copy PyTorch uses is shared). libpgx does not link RCCL.
+ *   pgx_rccl_unique_id    128 bytes made by ONE process and handed to the others by the caller's own means
+ *                         (a file, MPI, torch.distributed.broadcast_object_list ...)
+ *   pgx_rccl_comm_create  collective: every process calls it with the same id, its rank and the world size
+ *   pgx_rccl_comm_destroy (pgx_ctx_destroy does it too)
+ * The reference has no counterpart (its clustering is one cd-hit process, pangenome.py:444-447). */
+int pgx_rccl_load(const char *librccl_path);
+int pgx_rccl_unique_id(uint8_t *out_id128);
+int pgx_rccl_comm_create(pgx_ctx *ctx, const uint8_t *id128, int rank, int world);
+int pgx_rccl_comm_destroy(pgx_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------
  * Host side of the pipeline around the clustering call: multi-threaded FASTA

@@ -118,6 +118,10 @@ SIGNATURES = {
     'pgx_cluster_greedy': (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(ClusterParams), _P, _P, _P, _P,
                                      C.POINTER(C.c_uint32), C.POINTER(ClusterStats)]),
     'pgx_cluster_window_cap': (C.c_uint32, [C.POINTER(ClusterParams)]),
+    'pgx_rccl_load': (C.c_int, [_S]),
+    'pgx_rccl_unique_id': (C.c_int, [_P]),
+    'pgx_rccl_comm_create': (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    'pgx_rccl_comm_destroy': (C.c_int, [_P]),
     'pgx_cluster_greedy_dev': (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint64, C.POINTER(ClusterParams), _P, _P,
                                          _P, _P, C.POINTER(C.c_uint32), C.POINTER(ClusterStats), _P]),
 }
@@ -184,6 +188,32 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def rccl_path():
+    """The librccl.so this process should share: PyTorch-ROCm's bundled copy when there is one (found by path, without
+    importing torch), else whatever the loader finds. PGX_RCCL_LIB overrides."""
+    env = os.environ.get('PGX_RCCL_LIB')
+    if env:
+        return env
+    import importlib.util
+    spec = importlib.util.find_spec('torch')
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'librccl.so')
+        if os.path.exists(cand):
+            return cand
+    return 'librccl.so'
+
+
+def rccl_load(path=None):
+    check(lib().pgx_rccl_load((path or rccl_path()).encode()))
+
+
+def rccl_unique_id():
+    rccl_load()
+    buf = (C.c_uint8 * 128)()
+    check(lib().pgx_rccl_unique_id(C.cast(buf, _P)))
+    return bytes(buf)
+
+
 class Context(object):
     """Owns a pgx_ctx (device state). One per thread; not re-entrant."""
 
@@ -219,6 +249,22 @@ class Context(object):
                 'compute_units': info.compute_units, 'wavefront_size': info.wavefront_size,
                 'lds_bytes_per_block': info.lds_bytes_per_block, 'hbm_bytes': info.hbm_bytes,
                 'clock_khz': info.clock_khz}
+
+    # -- the library's own RCCL communicator (record-sharded mode without a callback) ----------
+    def comm_create(self, unique_id, rank, world):
+        """Collective: every process calls it with the same 128-byte id (rccl_unique_id() of one of them)."""
+        uid = bytes(unique_id)
+        if len(uid) != 128:
+            raise ValueError('the RCCL unique id is 128 bytes')
+        rccl_load()
+        check(lib().pgx_rccl_comm_create(self._h, C.cast(C.c_char_p(uid), _P), int(rank), int(world)))
+        self.comm = (int(rank), int(world))
+
+    def comm_destroy(self):
+        check(lib().pgx_rccl_comm_destroy(self._h))
+        self.comm = None
+
+    comm = None
 
     # -- per-kernel timing ---------------------------------------------------
     def profile(self, on=True):

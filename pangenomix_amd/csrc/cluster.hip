@@ -2248,7 +2248,12 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     PGX_REQUIRE(P->batch_size >= 0, "batch_size must not be negative");
     PGX_REQUIRE(P->shard_count >= 0 && (P->shard_count == 0 ? P->shard_index == 0 : (P->shard_index >= 0 && P->shard_index < P->shard_count)),
                 "shard_index must be in [0, shard_count)");
-    PGX_REQUIRE(P->shard_count <= 1 || P->exchange, "shard_count > 1 needs an exchange callback");
+    // the exchange of the record-sharded mode: the caller's callback, or the context's own RCCL communicator
+    const bool native_exchange = !P->exchange && P->shard_count >= 1 && ctx->comm;
+    const bool exchanging = P->exchange || native_exchange;
+    PGX_REQUIRE(P->shard_count <= 1 || exchanging, "shard_count > 1 needs an exchange callback or a communicator (pgx_rccl_comm_create)");
+    PGX_REQUIRE(!native_exchange || (ctx->comm_world == P->shard_count && ctx->comm_rank == P->shard_index),
+                "shard_index / shard_count differ from the rank / size of the context's communicator");
     PGX_REQUIRE(!P->exchange || (P->exchange_send && P->exchange_recv),
                 "the exchange callback needs exchange_send / exchange_recv (2 slots of PGX_EXCHANGE_WORDS uint64 per process, device memory)");
     PGX_HIP(hipSetDevice(ctx->device_id));
@@ -2395,7 +2400,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     uint32_t n_codes = 1;
     for (int t = 0; t < P->word_len; ++t) n_codes *= nt ? 4u : (uint32_t)kNAA1;
     const uint32_t window_cap = pgx_cluster_window_cap(P);           // queries per window
-    PGX_REQUIRE(!P->exchange || window_cap <= PGX_EXCHANGE_KEYS, "window larger than PGX_EXCHANGE_KEYS");
+    PGX_REQUIRE(!exchanging || window_cap <= PGX_EXCHANGE_KEYS, "window larger than PGX_EXCHANGE_KEYS");
     uint32_t pair_cap = 4u << 20;  // grows per window for nucleotides, whose word filter passes almost every pair
     // blocks: nucleotide rules pass nearly every pair, so 512 members (all their pairs fit); proteins 4096
     uint32_t block_cap = std::min(nt ? 512u : kBlockCap, window_cap);
@@ -2471,13 +2476,14 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         d_newbits, d_touched, d_first, d_best_own, d_rcvis, d_counters, d_visits, d_pairsW, d_pairsK, d_blk_list,
         d_ulist, d_new_list, d_flags, d_gscratch, d_order, d_list, d_gather, d_pk, d_pkoff,
         d_counters2, d_best2, d_flags2, d_pairsW2, d_gscratch2,   // second set of a window's own state (see `overlap`)
-        d_thr, d_hugewords;
+        d_thr, d_hugewords, d_xsend, d_xrecv;
     {   // all of them live in the context's workspace (slots 1..)
         DevBuf *all[] = {&d_res, &d_off, &d_len, &d_wcode, &d_wmult, &d_wcnt, &d_aa1, &d_aas, &d_aan, &d_lines,
                          &d_pool[0], &d_pool[1], &d_idx, &d_newbits, &d_touched, &d_first, &d_best_own, &d_rcvis,
                          &d_counters, &d_visits, &d_pairsW, &d_pairsK, &d_blk_list, &d_ulist, &d_new_list, &d_flags,
                          &d_gscratch, &d_order, &d_list, &d_gather, &d_pk, &d_pkoff,
-                         &d_counters2, &d_best2, &d_flags2, &d_pairsW2, &d_gscratch2, &d_thr, &d_hugewords};
+                         &d_counters2, &d_best2, &d_flags2, &d_pairsW2, &d_gscratch2, &d_thr, &d_hugewords,
+                         &d_xsend, &d_xrecv};
         int sl = 1;
         for (DevBuf *b : all) { b->ctx = ctx; b->slot = sl++; }
     }
@@ -2533,7 +2539,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     if (overlap) {
         PGX_HIP(d_counters2.alloc(C_COUNT * 4));
         PGX_HIP(hipMemsetAsync(d_counters2.p, 0, C_COUNT * 4, st));
-        if (!P->exchange) PGX_HIP(d_best2.alloc((size_t)window_cap * 8));
+        if (!exchanging) PGX_HIP(d_best2.alloc((size_t)window_cap * 8));
         PGX_HIP(d_flags2.alloc(4 * (size_t)window_cap));
         PGX_HIP(d_pairsW2.alloc((size_t)pair_cap * sizeof(Pair)));
         if (need_gscratch) PGX_HIP(d_gscratch2.alloc((size_t)diag_grid * gs_stride * 4));
@@ -2662,9 +2668,14 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     // record-sharded mode (see pgx.h): this process filters and aligns the window members ql % shard_count ==
     // shard_index; the window's best keys live in the caller's exchange buffer and are all-gathered after
     // every evaluation
-    unsigned long long *d_best = P->exchange ? static_cast<unsigned long long *>(P->exchange_send)
-                                             : d_best_own.as<unsigned long long>();
     const uint32_t shard_count = P->shard_count > 0 ? (uint32_t)P->shard_count : 1u;
+    if (native_exchange) {   // the library's own exchange buffers, laid out as pgx.h asks of a caller's
+        PGX_HIP(d_xsend.alloc((size_t)PGX_EXCHANGE_SLOTS * PGX_EXCHANGE_WORDS * 8));
+        PGX_HIP(d_xrecv.alloc((size_t)PGX_EXCHANGE_SLOTS * shard_count * PGX_EXCHANGE_WORDS * 8));
+    }
+    unsigned long long *const x_send = native_exchange ? d_xsend.as<unsigned long long>() : static_cast<unsigned long long *>(P->exchange_send);
+    const unsigned long long *const x_recv = native_exchange ? d_xrecv.as<unsigned long long>() : static_cast<const unsigned long long *>(P->exchange_recv);
+    unsigned long long *d_best = exchanging ? x_send : d_best_own.as<unsigned long long>();
     const uint32_t shard_index = P->shard_count > 0 ? (uint32_t)P->shard_index : 0u;
     const bool count_replicated = shard_index == 0;  // work every process repeats is counted by the first one only
     // test hook (tests/test_gpu_cluster_sharded.py): PGX_INJECT_ERROR="<rank>:<n>" makes that process report a pair
@@ -2673,7 +2684,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     uint64_t inject_at = 0, n_exchanges = 0;
     if (const char *e = std::getenv("PGX_INJECT_ERROR")) { unsigned long long at = 0; if (sscanf(e, "%d:%llu", &inject_rank, &at) == 2) inject_at = at; else inject_rank = -1; }
     uint64_t visits_rc = 0;
-    unsigned long long *const d_best_set[2] = {d_best, P->exchange ? d_best + PGX_EXCHANGE_WORDS : d_best2.as<unsigned long long>()};
+    unsigned long long *const d_best_set[2] = {d_best, exchanging ? d_best + PGX_EXCHANGE_WORDS : d_best2.as<unsigned long long>()};
     uint8_t *const d_flags_set[2] = {d_flags.as<uint8_t>(), d_flags2.as<uint8_t>()};
     std::vector<uint8_t> status(window_cap);
     HostVec<uint8_t> strand_of(ctx, 11, n, (uint8_t)0);
@@ -2697,7 +2708,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
     };
     auto window_error = [&](uint32_t e, uint32_t at) {   // (the word is the OR over all processes in the record-sharded mode)
         pgx_set_error("pgx_cluster_greedy: capacity failure in the window at %u%s:%s%s%s%s%s%s", at,
-                      P->exchange ? " (on this or another process)" : "",
+                      exchanging ? " (on this or another process)" : "",
                       e & E_TOUCHED ? " append scratch list full;" : "", e & E_POOL ? " overflow pool of the word index full;" : "",
                       e & E_TABLE ? " exact table of the filter overflowed;" : "",
                       e & E_BAND ? " alignment band wider than 64 diagonals;" : "", e & E_PAIRS ? " candidate pair buffer overflow;" : "",
@@ -2832,16 +2843,21 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         // record-sharded mode: every process learns every member's best key (one all-gather per evaluation,
         // enqueued on the stream by the caller's collective library; no host synchronisation)
         auto exchange_best = [&]() -> int {
-            if (!P->exchange) return PGX_OK;
+            if (!exchanging) return PGX_OK;
             ++n_exchanges;
             exchange_prepare_kernel<<<1, 1, 0, st>>>(dc, pair_cap, d_best,
                                                      inject_rank == (int)shard_index && inject_at == n_exchanges ? (uint32_t)E_PAIRS : 0u);
-            if (P->exchange(P->exchange_user, (void *)st, set) != 0) {
+            if (native_exchange) {
+                const int rc = pgx_rccl_all_gather_u64(ctx, x_send + (size_t)set * PGX_EXCHANGE_WORDS,
+                                                       const_cast<unsigned long long *>(x_recv) + (size_t)set * shard_count * PGX_EXCHANGE_WORDS,
+                                                       PGX_EXCHANGE_WORDS, st);
+                if (rc) return rc;
+            } else if (P->exchange(P->exchange_user, (void *)st, set) != 0) {
                 pgx_set_error("pgx_cluster_greedy: the exchange callback failed in the window at %u", b0);
                 return PGX_ERR_INTERNAL;
             }
             min_rows_kernel<<<(nb + 255) / 256, 256, 0, st>>>(
-                static_cast<const unsigned long long *>(P->exchange_recv) + (size_t)set * shard_count * PGX_EXCHANGE_WORDS,
+                x_recv + (size_t)set * shard_count * PGX_EXCHANGE_WORDS,
                 shard_count, PGX_EXCHANGE_WORDS, nb, d_best, dc + C_ERR);
             LAUNCH_CHECK();
             return PGX_OK;

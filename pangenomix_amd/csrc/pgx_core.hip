@@ -185,6 +185,7 @@ int pgx_ctx_create_on(const int *device_ids, int n_devices, pgx_ctx **out) {
 
 void pgx_ctx_destroy(pgx_ctx *ctx) {
     if (!ctx) return;
+    (void)pgx_rccl_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device_id);
     // both streams drained before anything they may still read or write is released
     (void)hipStreamSynchronize(ctx->stream);

@@ -43,6 +43,9 @@ struct pgx_ctx {
     // the gene x genome bitmap a pipeline left on the device (pgx_bitmap_from_clusters): its token, shape, buffer
     uint64_t resident_token = 0, resident_next = 1;
     uint32_t resident_genes = 0, resident_genomes = 0;
+    // the library's own RCCL communicator (pgx_rccl_comm_create): the record-sharded exchange without a callback
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
 };
 
 // Array of n elements of T in the context's host scratch slot `slot` (uninitialised unless `fill` is given).
@@ -155,3 +158,6 @@ static inline uint32_t ceil_div_u32(uint32_t a, uint32_t b) { return (a + b - 1)
 // take the plain call. Returns when every chunk has been ENQUEUED (the source may be reused; the copies complete in
 // stream order).
 int pgx_staged_h2d(pgx_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t stream);
+
+// all-gather of `count` uint64 per process with the context's RCCL communicator, enqueued on `stream` (rccl_exchange.hip)
+int pgx_rccl_all_gather_u64(pgx_ctx *ctx, const void *send, void *recv, size_t count, hipStream_t stream);

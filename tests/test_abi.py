@@ -46,3 +46,13 @@ def test_no_cpu_fallback_without_a_device():
         pytest.skip('a GPU is present')
     with pytest.raises(_native.PgxError, match='no usable HIP device|no CPU fallback'):
         _native.Context(0)
+
+
+def test_rccl_is_loaded_on_request_only_and_a_bad_path_is_an_error():
+    """libpgx does not link RCCL: the collective library is dlopen'ed by path (pgx_rccl_load). A path that does not
+    exist is PGX_ERR_INVALID with the loader's message, and without a communicator a sharded call is refused."""
+    with pytest.raises(_native.PgxError, match='pgx_rccl_load'):
+        _native.rccl_load('/nonexistent/librccl.so')
+    needed = os.popen('readelf -d %s' % os.path.join(ROOT, 'pangenomix_amd', 'libpgx.so')).read()
+    assert 'rccl' not in needed
+    assert os.path.basename(_native.rccl_path()).startswith('librccl')

@@ -132,6 +132,30 @@ def test_single_rank_group_is_the_plain_path(gpu_ctx):
     assert_same(got, oracle.cluster_greedy(res, off, p))
 
 
+def test_single_rank_native_rccl_exchange_is_the_plain_path():
+    """world = 1 with the library's own communicator (pgx_rccl_*): ncclAllGather enqueued by libpgx on the window's
+    stream instead of the callback. Same result as the oracle; a second call reuses the communicator; a context whose
+    communicator has another rank / size than the parameters is refused. (More than one rank needs one GPU each:
+    RCCL refuses two ranks on one card, so the multi-rank logic is covered by the virtual ranks above and the
+    collective itself here.)"""
+    res, off, _ = synth.protein_set('small').nr_arrays()
+    p = params()
+    want = oracle.cluster_greedy(res, off, p)
+    with _native.Context(0) as ctx:
+        ctx.comm_create(_native.rccl_unique_id(), 0, 1)
+        sp = cluster.native_shard_params(p, 0, 1)
+        assert not sp.exchange and sp.shard_count == 1
+        for _ in range(2):
+            assert_same(ctx.cluster_greedy(res, off, sp), want)
+        bad = cluster.native_shard_params(p, 0, 2)
+        with pytest.raises(_native.PgxError, match='communicator'):
+            ctx.cluster_greedy(res, off, bad)
+        with pytest.raises(_native.PgxError, match='already'):
+            ctx.comm_create(_native.rccl_unique_id(), 0, 1)
+        ctx.comm_destroy()
+        assert_same(ctx.cluster_greedy(res, off, p), want)      # and the context is an ordinary one again
+
+
 def test_bad_shard_arguments_are_rejected(gpu_ctx):
     res, off, _ = synth.protein_set('tiny').nr_arrays()
     p = params()
