@@ -365,6 +365,17 @@ int pgx_format_labels(const char *prefix, const char *variant, const int32_t *cl
 int pgx_format_labels_ucs4(const char *prefix, const char *variant, const int32_t *cluster, const int32_t *member,
                            uint64_t n, uint32_t width, uint32_t *out);
 
+/* The two orderings of the feature tables (build_genetic_feature_tables, pangenome.py:563-680), host code:
+ *   pgx_allele_order      out_order[i] = position of the i-th allele when the names <prefix><cluster><letter><member>
+ *                         are sorted as strings (:615 sorts the names; here two stable radix passes over keys that
+ *                         order integers like their decimal strings). cluster, member >= 0, n < 2^32.
+ *   pgx_first_insertions  the triples a dictionary-of-keys matrix keeps when (rows[i], cols[i]) are set one after the
+ *                         other (:649-650): out_first[0..*out_count) = ascending positions whose pair occurs there for
+ *                         the first time (room for n entries). 0 <= cols[i] < n_cols, rows[i] >= 0. */
+int pgx_allele_order(const int32_t *cluster, const int32_t *member, uint64_t n, int64_t *out_order);
+int pgx_first_insertions(const int64_t *rows, const int64_t *cols, uint64_t n, uint64_t n_cols, int64_t *out_first,
+                         uint64_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,8 @@ SIGNATURES = {
                                           C.POINTER(C.c_uint64)]),
     'pgx_bitmap_resident_read': (C.c_int, [_P, C.c_uint64, _P]),
     'pgx_pan_core_table_resident': (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_int32), C.c_uint32, _P, _P]),
+    'pgx_allele_order': (C.c_int, [_P, _P, C.c_uint64, _P]),
+    'pgx_first_insertions': (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     'pgx_format_labels': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_format_labels_ucs4': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_fasta_write_clustered': (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _S, _S, _S, _S, _S]),
@@ -481,6 +483,12 @@ class FastaSet(object):
         except Exception:
             pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def _view(self, fn, dtype, n):
         """numpy view (no copy) of one of the library's arrays; valid until close()."""
         ptr = getattr(lib(), fn)(self._h)
@@ -545,6 +553,29 @@ def format_labels(prefix, cluster, member=None, variant=None):
     check(lib().pgx_format_labels(prefix.encode(), variant.encode() if variant is not None else None, _ptr(cluster),
                                   _ptr(member) if variant is not None else None, cluster.size, width, _ptr(out)))
     return np.char.decode(out, 'utf-8')
+
+
+def allele_order(cluster, member):
+    """Positions of the (cluster, member) pairs in the order of their allele names sorted as strings (stable)."""
+    cluster = np.ascontiguousarray(cluster, dtype=np.int32)
+    member = np.ascontiguousarray(member, dtype=np.int32)
+    if cluster.shape != member.shape or cluster.ndim != 1:
+        raise ValueError('cluster and member must be 1-D arrays of one length')
+    out = np.empty(cluster.size, dtype=np.int64)
+    check(lib().pgx_allele_order(_ptr(cluster), _ptr(member), cluster.size, _ptr(out)))
+    return out
+
+
+def first_insertions(rows, cols, n_cols):
+    """Ascending positions i at which the pair (rows[i], cols[i]) occurs for the first time."""
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    if rows.shape != cols.shape or rows.ndim != 1:
+        raise ValueError('rows and cols must be 1-D arrays of one length')
+    out = np.empty(rows.size, dtype=np.int64)
+    m = C.c_uint64(0)
+    check(lib().pgx_first_insertions(_ptr(rows), _ptr(cols), rows.size, int(max(n_cols, 1)), _ptr(out), C.byref(m)))
+    return out[:m.value]
 
 
 _default_ctx = None

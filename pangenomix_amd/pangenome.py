@@ -284,11 +284,10 @@ def _first_occurrence_coo(rows, cols, n_rows, n_cols):
     """COO with ones, duplicates dropped, triples in order of first insertion:
     the order scipy's dok_matrix.tocoo() yields for the reference's loop
     (:649-650), pinned by tests/golden/cds."""
-    import pandas as pd
+    from . import _native
     rows = np.asarray(rows, dtype=np.int64)
     cols = np.asarray(cols, dtype=np.int64)
-    flat = rows * max(n_cols, 1) + cols
-    first = np.flatnonzero(~pd.Series(flat).duplicated().values)     # hash-based: linear, keeps the order
+    first = _native.first_insertions(rows, cols, n_cols)            # hash-based: linear, keeps the order
     data = np.ones(first.size, dtype=np.int64)
     return scipy.sparse.coo_matrix(
         (data, (rows[first].astype(np.int32), cols[first].astype(np.int32))),
@@ -474,11 +473,7 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         genome_order = sorted(genomes)
         print('Sorting alleles...')
         clustered = np.flatnonzero(cl >= 0)
-        k_mem, k_cl = _lex_key(mem[clustered], True), _lex_key(cl[clustered], False)
-        if k_mem.size and int(k_mem.max()).bit_length() + int(k_cl.max()).bit_length() <= 62:   # one key, one sort
-            order = np.argsort((k_cl << int(k_mem.max()).bit_length()) | k_mem, kind='stable')
-        else:
-            order = np.lexsort((k_mem, k_cl))
+        order = _native.allele_order(cl[clustered], mem[clustered])   # (= np.lexsort of the _lex_key()s above)
         allele_groups = clustered[order]                       # groups in allele-row order
         row_of_group = np.full(fs.n_groups, -1, dtype=np.int64)
         row_of_group[allele_groups] = np.arange(allele_groups.size)
@@ -544,7 +539,10 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
 def _save_both(df_alleles, allele_npz, df_genes, gene_npz):
     """The two tables of a pangenome, written side by side (the deflate of the .npz members releases the GIL);
     the messages come in the reference's order."""
+    import sys
     import threading
+    import time
+    t0 = time.perf_counter()
     print('Saving', allele_npz, '...')
     errors = []
 
@@ -562,6 +560,8 @@ def _save_both(df_alleles, allele_npz, df_genes, gene_npz):
         t.join()
     if errors:
         raise errors[0]
+    if os.environ.get('PGX_TRACE'):
+        print('[pgx] pipeline: %-28s %8.1f ms' % ('.npz + labels', (time.perf_counter() - t0) * 1e3), file=sys.stderr)
 
 
 def _check_format(output_format):

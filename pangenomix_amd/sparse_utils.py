@@ -18,6 +18,76 @@ import numpy as np
 import scipy.sparse
 
 
+_deflate_pool = None
+
+
+def _pool():
+    global _deflate_pool
+    if _deflate_pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _deflate_pool = ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1)))
+    return _deflate_pool
+
+
+def _deflate_chunk(args):
+    import zlib
+    part, last = args
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)            # raw deflate, as a zip member holds it
+    return co.compress(part) + co.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH)
+
+
+def write_npz_parallel(path, members, chunk=1 << 20):
+    """A .npz (zip of deflated .npy members, as numpy.savez_compressed / scipy.sparse.save_npz write) whose members are
+    deflated in 1 MB pieces by a pool of threads (zlib releases the GIL): a piece that is not the last ends with a
+    sync flush -- a byte-aligned empty block -- so the pieces put end to end are one deflate stream (what pigz does).
+    `members`: (name, array) pairs. Members of 4 GiB or more are left to the caller (zip64)."""
+    import io
+    import struct
+    import time
+    import zlib
+    entries, jobs = [], []
+    for name, arr in members:
+        arr = np.asarray(arr)
+        if not arr.flags.c_contiguous:
+            arr = np.ascontiguousarray(arr)                   # (never for a 0-d array, which it would make 1-d)
+        head = io.BytesIO()
+        np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(arr))
+        body = arr.tobytes() if arr.ndim == 0 or arr.nbytes < chunk else memoryview(arr.reshape(-1)).cast('B')
+        raw = [head.getvalue() + bytes(body)] if len(body) < chunk else None
+        if raw is None:     # the header travels with the first piece
+            raw = [head.getvalue() + bytes(body[:chunk])] + [body[o:o + chunk] for o in range(chunk, len(body), chunk)]
+        usize = sum(len(r) for r in raw)
+        if usize >= 0xFFFFFFFF:
+            raise OverflowError('member of 4 GiB or more')
+        crc = 0
+        for r in raw:
+            crc = zlib.crc32(r, crc)
+        entries.append([name + '.npy', crc, usize, len(jobs), len(raw)])
+        jobs.extend((r, i == len(raw) - 1) for i, r in enumerate(raw))
+    packed = list(_pool().map(_deflate_chunk, jobs))
+    t = time.localtime()
+    dos_time = (t.tm_hour << 11) | (t.tm_min << 5) | (t.tm_sec // 2)
+    dos_date = (max(t.tm_year, 1980) - 1980) << 9 | (t.tm_mon << 5) | t.tm_mday
+    central, offset = [], 0
+    with open(path, 'wb') as f:
+        for name, crc, usize, j0, nj in entries:
+            fname = name.encode('ascii')
+            csize = sum(len(packed[j]) for j in range(j0, j0 + nj))
+            if csize >= 0xFFFFFFFF:
+                raise OverflowError('member of 4 GiB or more')
+            fixed = (20, 0, 8, dos_time, dos_date, crc & 0xFFFFFFFF, csize, usize, len(fname), 0)
+            f.write(struct.pack('<4s5H3L2H', b'PK\x03\x04', *fixed))
+            f.write(fname)
+            for j in range(j0, j0 + nj):
+                f.write(packed[j])
+            central.append(struct.pack('<4s6H3L5H2L', b'PK\x01\x02', (3 << 8) | 20, *fixed, 0, 0, 0, 0o600 << 16, offset) + fname)
+            offset += 30 + len(fname) + csize
+        cd = b''.join(central)
+        f.write(cd)
+        f.write(struct.pack('<4s4H2LH', b'PK\x05\x06', 0, 0, len(central), len(central), len(cd), offset, 0))
+
+
 def read_lsdf(npz_file, label_file=None):
     """Load an LSDF from `<npz_file>` + `<npz_file>.labels.txt`.
 
@@ -82,7 +152,8 @@ class LightSparseDataFrame(object):
         """Write `<npz_file>` and its label file (reference :295-314). The .npz holds what
         scipy.sparse.save_npz writes for the COO matrix -- members row, col, format, shape, data with the
         same dtypes, deflated -- at the fastest deflate level (the default level spends 1.7 s on the
-        400-genome allele table, this 0.3 s; readers do not see the difference)."""
+        400-genome allele table, this 0.3 s; readers do not see the difference) and in pieces by several threads
+        (write_npz_parallel)."""
         import zipfile
         label_path = npz_file + '.labels.txt' if label_file is None else label_file
         with open(label_path, 'w+') as f:
@@ -96,10 +167,13 @@ class LightSparseDataFrame(object):
                    ('shape', np.array(m.shape, dtype=np.int64)), ('data', m.data))
         if not npz_file.endswith('.npz'):
             npz_file += '.npz'      # (as numpy.savez does)
-        with zipfile.ZipFile(npz_file, 'w', zipfile.ZIP_DEFLATED, compresslevel=1) as z:
-            for name, arr in members:
-                with z.open(name + '.npy', 'w', force_zip64=True) as f:
-                    np.lib.format.write_array(f, np.asanyarray(arr), allow_pickle=False)
+        try:
+            write_npz_parallel(npz_file, members)
+        except OverflowError:       # a member of 4 GiB or more: the zip64 writer of the standard library
+            with zipfile.ZipFile(npz_file, 'w', zipfile.ZIP_DEFLATED, compresslevel=1) as z:
+                for name, arr in members:
+                    with z.open(name + '.npy', 'w', force_zip64=True) as f:
+                        np.lib.format.write_array(f, np.asanyarray(arr), allow_pickle=False)
 
     # -- small helpers used by downstream consumers ------------------------
     def transpose(self):

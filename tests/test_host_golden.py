@@ -154,3 +154,23 @@ def test_label_maps_are_the_construction_time_maps():
     df.column_map = {'a': 0, 'b': 1}
     assert df.labelslice(columns=['b']).values.tolist() == [[0], [1]]
     assert df.index_map == {'g0': 0, 'g1': 1}
+
+
+def test_npz_members_deflated_in_pieces_read_back_whole(tmp_path):
+    """to_npz() deflates a member in 1 MB pieces on several threads and puts the pieces end to end
+    (sparse_utils.write_npz_parallel): the standard readers must see one intact member -- compressible and
+    incompressible data, sizes around the piece boundary, a 0-d and an empty member, a transposed view."""
+    import zipfile
+    rng = np.random.default_rng(3)
+    piece = 1 << 14
+    members = [('noise', rng.integers(0, 1 << 62, 5 * piece // 8 + 3)), ('ones', np.ones(3 * piece // 8, dtype=np.int64)),
+               ('edge', np.arange((piece - 128) // 4, dtype=np.int32)), ('edge1', np.arange((piece - 128) // 4 + 1, dtype=np.int32)),
+               ('format', np.array(b'coo')), ('empty', np.zeros(0, dtype=np.int32)), ('view', np.arange(12).reshape(3, 4).T)]
+    path = str(tmp_path / 'm.npz')
+    su.write_npz_parallel(path, members, chunk=piece)
+    with zipfile.ZipFile(path) as z:
+        assert z.testzip() is None
+        assert [i.filename for i in z.infolist()] == [n + '.npy' for n, _ in members]
+    with np.load(path) as got:
+        for name, arr in members:
+            assert got[name].dtype == arr.dtype and got[name].shape == arr.shape and (got[name] == arr).all(), name

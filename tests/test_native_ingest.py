@@ -229,6 +229,43 @@ def test_lex_key_orders_like_the_names():
     assert [names[i] for i in order] == sorted(names)
 
 
+def test_native_allele_order_sorts_like_the_names():
+    """pgx_allele_order: the row order of the allele table = the names sorted as strings (pangenome.py:615), stable for
+    equal pairs, over ranges where the digit counts differ; and it equals the numpy restatement above."""
+    from pangenomix_amd import _native
+    rng = np.random.default_rng(1)
+    for cmax, mmax, n in ((3000, 300, 5000), (12, 4, 200), (2_000_000_000, 150_000, 4000), (1, 1, 3)):
+        c = np.concatenate([rng.integers(0, cmax, n), [0, 1, 9, 10, 11, 99, 100, 101, 999, 1000, cmax]]).astype(np.int32)
+        m = np.concatenate([rng.integers(0, mmax, n), [0, 1, 9, 10, 11, 99, 100, 101, 7, 3, mmax]]).astype(np.int32)
+        names = ['N_C%dA%d' % cm for cm in zip(c.tolist(), m.tolist())]
+        order = _native.allele_order(c, m)
+        assert sorted(order.tolist()) == list(range(c.size))
+        assert [names[i] for i in order] == sorted(names)
+        assert order.tolist() == np.lexsort((pg._lex_key(m, True), pg._lex_key(c, False))).tolist()   # (both stable)
+    assert _native.allele_order(np.zeros(0, np.int32), np.zeros(0, np.int32)).size == 0
+    with pytest.raises(_native.PgxError, match='negative'):
+        _native.allele_order(np.array([1, -1], np.int32), np.array([0, 0], np.int32))
+
+
+def test_native_first_insertions_keep_the_dictionary_order():
+    """pgx_first_insertions against a Python dict filled pair by pair (what scipy's dok_matrix is, pangenome.py:649-650)."""
+    from pangenomix_amd import _native
+    rng = np.random.default_rng(2)
+    for n, n_rows, n_cols in ((20000, 300, 7), (5000, 1 << 40, 3), (10, 1, 1), (0, 5, 5)):
+        rows = rng.integers(0, n_rows, n)
+        cols = rng.integers(0, n_cols, n)
+        seen, want = {}, []
+        for i, rc in enumerate(zip(rows.tolist(), cols.tolist())):
+            if rc not in seen:
+                seen[rc] = 1
+                want.append(i)
+        assert _native.first_insertions(rows, cols, n_cols).tolist() == want
+    with pytest.raises(_native.PgxError, match='out of range'):
+        _native.first_insertions(np.array([0, 1]), np.array([0, 5]), 5)
+    with pytest.raises(_native.PgxError, match='out of range'):
+        _native.first_insertions(np.array([-1]), np.array([0]), 5)
+
+
 def test_format_labels_matches_python_formatting():
     """Feature names from the library (numpy 'U' records written by several threads; the 'S' path for a
     prefix that is not ASCII) equal the reference's string formatting (pangenome.py:1944-1969)."""
@@ -243,3 +280,36 @@ def test_format_labels_matches_python_formatting():
         assert alleles.tolist() == ['%s%dA%d' % (prefix, a, b) for a, b in zip(c.tolist(), m.tolist())]
         assert genes.tolist() == ['%s%d' % (prefix, a) for a in c.tolist()]
     assert _native.format_labels('X', np.zeros(0, dtype=np.int32)).shape == (0,)
+
+
+def test_clustered_outputs_with_member_numbers_that_are_not_consecutive(tmp_path):
+    """pgx_fasta_write_clustered places every sequence at (start of its cluster + member number) when a cluster's members
+    are numbered 0, 1, 2, ... and sorts otherwise: numbers with gaps, a repeated number, cluster numbers far apart and
+    unclustered sequences give the same .clstr as the Python writer (cluster, then member number, then input order)."""
+    from pangenomix_amd import _native
+    rng = np.random.default_rng(5)
+    src = tmp_path / 'g'
+    src.mkdir()
+    paths = random_fasta_set(rng, str(src), quirks=False)
+    with _native.FastaSet(paths) as fs:
+        n = fs.n_groups
+        headers = fs.headers(fs.rep_of_group)
+        lengths = np.diff(fs.offsets.astype(np.int64))
+        iden = rng.uniform(0.8, 1.0, n).astype(np.float32)
+        cases = {'consecutive': (np.arange(n) // 4, np.arange(n) % 4),
+                 'gaps': (np.arange(n) // 4, 2 * (np.arange(n) % 4)),
+                 'repeated': (np.arange(n) // 4, np.minimum(np.arange(n) % 4, 2)),
+                 'sparse clusters': (1000003 * (np.arange(n) // 4), np.arange(n) % 4),
+                 'some unclustered': (np.where(np.arange(n) % 7 == 3, -1, np.arange(n) // 5), np.arange(n) % 5)}
+        for what, (cl, mem) in cases.items():
+            perm = rng.permutation(n)                      # (the sequences are not in cluster order)
+            cl, mem = cl[perm].astype(np.int32), mem[perm].astype(np.int32)
+            got, want = str(tmp_path / 'got.clstr'), str(tmp_path / 'want.clstr')
+            fs.write_clustered(cl, mem, iden, None, False, 'X_C', 'A', clstr_path=got, names_path=str(tmp_path / 'names.tsv'),
+                               nr_out_path=str(tmp_path / 'nr.faa'))
+            cluster.write_clstr(want, headers, lengths, cl, mem, iden, np.zeros(n, np.uint8), False)
+            assert filecmp.cmp(got, want, shallow=False), what
+            names = [ln.split('\t')[0] for ln in open(str(tmp_path / 'names.tsv'))]
+            keep = np.flatnonzero(cl >= 0)
+            order = keep[np.lexsort((keep, mem[keep], cl[keep]))]
+            assert names == ['X_C%dA%d' % (cl[i], mem[i]) for i in order], what
