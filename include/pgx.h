@@ -373,6 +373,18 @@ int pgx_format_labels_ucs4(const char *prefix, const char *variant, const int32_
  *                         other (:649-650): out_first[0..*out_count) = ascending positions whose pair occurs there for
  *                         the first time (room for n entries). 0 <= cols[i] < n_cols, rows[i] >= 0. */
 int pgx_allele_order(const int32_t *cluster, const int32_t *member, uint64_t n, int64_t *out_order);
+/* Both tables' coordinates in one pass over a parsed set (the loops of pangenome.py:598-650 for inputs where every file is
+ * one genome): cluster / member per non-redundant sequence as for pgx_fasta_write_clustered; file_order = the files in
+ * the order their records are inserted (the reference walks sorted(paths)), genome_of_file = each file's column, both
+ * permutations of 0..n_files-1. Out: allele_groups[i] = the sequence of allele row i (rows in pgx_allele_order's order),
+ * gene_of_allele[i] = its gene row (room for n_groups each), *n_alleles, *n_genes; the COO triples of the allele and the
+ * gene table in first-insertion order (a_row/a_col, g_row/g_col: room for n_records each; all values are 1);
+ * lost_records = records that have no row (a sequence without a name, or one the clustering discarded), in
+ * insertion order (room for n_records). */
+int pgx_fasta_feature_coo(const pgx_fasta_set *fs, const int32_t *cluster, const int32_t *member, const int32_t *file_order,
+                          const int32_t *genome_of_file, int64_t *allele_groups, int32_t *gene_of_allele, uint64_t *n_alleles,
+                          uint64_t *n_genes, int32_t *a_row, int32_t *a_col, uint64_t *a_nnz, int32_t *g_row, int32_t *g_col,
+                          uint64_t *g_nnz, int64_t *lost_records, uint64_t *n_lost);
 int pgx_first_insertions(const int64_t *rows, const int64_t *cols, uint64_t n, uint64_t n_cols, int64_t *out_first,
                          uint64_t *out_count);
 

@@ -89,6 +89,8 @@ SIGNATURES = {
     'pgx_bitmap_resident_read': (C.c_int, [_P, C.c_uint64, _P]),
     'pgx_pan_core_table_resident': (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_int32), C.c_uint32, _P, _P]),
     'pgx_allele_order': (C.c_int, [_P, _P, C.c_uint64, _P]),
+    'pgx_fasta_feature_coo': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P, _P,
+                                       C.POINTER(C.c_uint64), _P, _P, C.POINTER(C.c_uint64), _P, C.POINTER(C.c_uint64)]),
     'pgx_first_insertions': (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.POINTER(C.c_uint64)]),
     'pgx_format_labels': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
     'pgx_format_labels_ucs4': (C.c_int, [_S, _S, _P, _P, C.c_uint64, C.c_uint32, _P]),
@@ -473,9 +475,9 @@ class FastaSet(object):
         self._n_res, self._n_hdr = int(info.n_residue_bytes), int(info.n_header_bytes)
 
     def close(self):
-        if self._h:
-            lib().pgx_fasta_close(self._h)
-            self._h = C.c_void_p()
+        h, self._h = self._h, C.c_void_p()      # (taken first: a second caller, e.g. __del__ on another thread, finds nothing)
+        if h:
+            lib().pgx_fasta_close(h)
 
     def __del__(self):
         try:
@@ -516,6 +518,27 @@ class FastaSet(object):
     def write_consolidated(self, nr_path, shared_path, missing_path=None):
         check(lib().pgx_fasta_write_consolidated(self._h, os.fsencode(nr_path) if nr_path else None, os.fsencode(shared_path),
                                                  os.fsencode(missing_path) if missing_path else None))
+
+    def feature_coo(self, cluster, member, file_order, genome_of_file):
+        """Coordinates of the allele and the gene table (pgx_fasta_feature_coo). Returns a dict: allele_groups,
+        gene_of_allele, n_genes, a_row, a_col, g_row, g_col, lost_records."""
+        cluster = np.ascontiguousarray(cluster, dtype=np.int32)
+        member = np.ascontiguousarray(member, dtype=np.int32)
+        file_order = np.ascontiguousarray(file_order, dtype=np.int32)
+        genome_of_file = np.ascontiguousarray(genome_of_file, dtype=np.int32)
+        if not (cluster.size == member.size == self.n_groups) or file_order.size != genome_of_file.size:
+            raise ValueError('one entry per non-redundant sequence / per file expected')
+        groups = np.empty(self.n_groups, dtype=np.int64)
+        gene_of = np.empty(self.n_groups, dtype=np.int32)
+        coo = [np.empty(self.n_records, dtype=np.int32) for _ in range(4)]
+        lost = np.empty(self.n_records, dtype=np.int64)
+        n = [C.c_uint64(0) for _ in range(5)]    # alleles, genes, allele triples, gene triples, lost records
+        check(lib().pgx_fasta_feature_coo(self._h, _ptr(cluster), _ptr(member), _ptr(file_order), _ptr(genome_of_file),
+                                          _ptr(groups), _ptr(gene_of), C.byref(n[0]), C.byref(n[1]), _ptr(coo[0]), _ptr(coo[1]),
+                                          C.byref(n[2]), _ptr(coo[2]), _ptr(coo[3]), C.byref(n[3]), _ptr(lost), C.byref(n[4])))
+        na, ng, ta, tg, nl = (int(x.value) for x in n)
+        return {'allele_groups': groups[:na], 'gene_of_allele': gene_of[:na], 'n_genes': ng, 'a_row': coo[0][:ta],
+                'a_col': coo[1][:ta], 'g_row': coo[2][:tg], 'g_col': coo[3][:tg], 'lost_records': lost[:nl]}
 
     def write_clustered(self, cluster, member, identity, strand, nucleotide, prefix, variant,
                         clstr_path=None, names_path=None, nr_out_path=None):

@@ -21,6 +21,7 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -201,6 +202,36 @@ void parse_file(FileData &F, uint32_t file_id) {
         if (F.recs[r].seq_len) sha256(F.seq.data() + F.recs[r].seq_off, F.recs[r].seq_len, &F.digest[r * 32]);
 }
 
+// Cores this process may really use: the smallest of the hardware's count, the affinity mask and the cgroup's CPU
+// quota (containers: 256 hardware threads visible, 16 allowed -- more runnable threads than the quota only get the
+// whole group throttled).
+unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    auto quota = [&](const char *path, bool v2) {
+        FILE *f = fopen(path, "r");
+        if (!f) return;
+        char a[64] = "", b[64] = "";
+        if (v2) {
+            if (fscanf(f, "%63s %63s", a, b) == 2 && strcmp(a, "max") != 0) {
+                const double q = atof(a), per = atof(b);
+                if (q > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max(1.0, q / per + 0.5));
+            }
+        } else if (fscanf(f, "%63s", a) == 1) {
+            const double q = atof(a);
+            FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            double per = 100000;
+            if (g) { if (fscanf(g, "%63s", b) == 1 && atof(b) > 0) per = atof(b); fclose(g); }
+            if (q > 0) n = std::min<unsigned>(n, (unsigned)std::max(1.0, q / per + 0.5));
+        }
+        fclose(f);
+    };
+    quota("/sys/fs/cgroup/cpu.max", true);
+    quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+    return n;
+}
+
 // An exception in a worker (std::bad_alloc from the vectors and strings the items grow) must not reach
 // std::terminate: the workers catch, the first failure stops the hand-out of items, and the CALLING thread throws
 // once everybody has joined -- from there the guards of the C ABI (`guarded`) turn it into a status code.
@@ -318,8 +349,12 @@ static int pgx_fasta_open_impl(const char *const *paths, uint32_t n_paths, int n
     *out = nullptr;
     std::unique_ptr<pgx_fasta_set> holder(new pgx_fasta_set());   // (released to the caller at the end; freed on every other way out)
     pgx_fasta_set *S = holder.get();
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    // (the writers format in memory: one thread per usable core; the readers here wait for files and fresh pages, and
+    // twice as many keep the cores busy: 155 ms against 200 ms for the benchmark's 400 files on a 16-core quota)
+    const bool automatic = n_threads <= 0;
+    if (automatic) n_threads = (int)std::max(1u, std::min(32u, usable_cpus()));
     S->threads = n_threads;
+    if (automatic) n_threads = std::min(32, 2 * n_threads);
     S->files.resize(n_paths);
     for (uint32_t i = 0; i < n_paths; ++i) S->paths.emplace_back(paths[i]);
     const bool trace = std::getenv("PGX_TRACE") != nullptr;
@@ -800,7 +835,7 @@ static int pgx_legacy_shuffles_impl(uint32_t *key, int32_t *pos, uint32_t n, uin
     lap_("count done");
     // (2) the swaps, iterations spread over a few cores (helpers that SPIN beside the count, waiting for batches, cost
     // more than they gain on hosts with a CPU quota)
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = usable_cpus();
     const int threads = (size_t)n_iter * n < (1u << 16) ? 1 : (int)std::min(8u, hw);
     constexpr size_t kBatch = 8;
     parallel_for(((size_t)n_iter + kBatch - 1) / kBatch, threads, [&](size_t w) {
@@ -855,7 +890,7 @@ static int pgx_format_labels_ucs4_impl(const char *prefix, const char *variant, 
     for (size_t i = 0; i < vl; ++i) if ((unsigned char)variant[i] >= 128) { pgx_set_error("pgx_format_labels_ucs4: variant is not ASCII"); return PGX_ERR_INVALID; }
     std::atomic<int> bad{0};
     const size_t chunk = 1u << 15;
-    parallel_for((size_t)((n + chunk - 1) / chunk), (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())), [&](size_t c) {
+    parallel_for((size_t)((n + chunk - 1) / chunk), (int)std::max(1u, std::min(16u, usable_cpus())), [&](size_t c) {
         auto put_int = [](uint32_t *o, int32_t v) -> size_t {     // decimal digits of v >= 0 (names never hold negatives)
             char tmp[12];
             size_t k = 0;
@@ -972,7 +1007,102 @@ static int pgx_first_insertions_impl(const int64_t *rows, const int64_t *cols, u
     return PGX_OK;
 }
 
+/* The coordinates of both feature tables straight from the parsed files and the clustering result
+ * (build_genetic_feature_tables, pangenome.py:563-680): see pgx.h. Files are independent -- every file is one genome, so a
+ * pair can only repeat inside a file -- and are worked on side by side, each with a small table of its own. */
+static int pgx_fasta_feature_coo_impl(const pgx_fasta_set *S, const int32_t *cluster, const int32_t *member,
+                                      const int32_t *file_order, const int32_t *genome_of_file, int64_t *allele_groups,
+                                      int32_t *gene_of_allele, uint64_t *n_alleles, uint64_t *n_genes, int32_t *a_row,
+                                      int32_t *a_col, uint64_t *a_nnz, int32_t *g_row, int32_t *g_col, uint64_t *g_nnz,
+                                      int64_t *lost_records, uint64_t *n_lost) {
+    if (!S || !S->simple || !cluster || !member || !file_order || !genome_of_file || !allele_groups || !gene_of_allele ||
+        !n_alleles || !n_genes || !a_row || !a_col || !a_nnz || !g_row || !g_col || !g_nnz || !lost_records || !n_lost) {
+        pgx_set_error("pgx_fasta_feature_coo: invalid argument");
+        return PGX_ERR_INVALID;
+    }
+    const uint64_t G = S->n_groups, NF = S->files.size();
+    {   // every file once in file_order, every genome once
+        std::vector<uint8_t> seen_file(NF, 0), seen_genome(NF, 0);
+        for (uint64_t i = 0; i < NF; ++i) {
+            const int32_t f = file_order[i], g = f >= 0 && (uint64_t)f < NF ? genome_of_file[f] : -1;
+            if (g < 0 || (uint64_t)g >= NF || seen_file[(size_t)f]++ || seen_genome[(size_t)g]++) {
+                pgx_set_error("pgx_fasta_feature_coo: file_order / genome_of_file must be permutations of the files");
+                return PGX_ERR_INVALID;
+            }
+        }
+    }
+    // rows of the allele table: the clustered groups in the order of their names; genes: runs of one cluster
+    std::vector<int32_t> cl_c, mem_c;
+    std::vector<uint32_t> group_c;
+    for (uint64_t k = 0; k < G; ++k) if (cluster[k] >= 0) { cl_c.push_back(cluster[k]); mem_c.push_back(member[k]); group_c.push_back((uint32_t)k); }
+    const uint64_t A = cl_c.size();
+    std::vector<int64_t> order(A);
+    const int rc = pgx_allele_order_impl(cl_c.data(), mem_c.data(), A, order.data());
+    if (rc) return rc;
+    std::vector<int32_t> row_of_group(G, -1);
+    int32_t gene = -1;
+    for (uint64_t i = 0; i < A; ++i) {
+        const uint32_t k = group_c[(size_t)order[i]];
+        allele_groups[i] = (int64_t)k;
+        row_of_group[k] = (int32_t)i;
+        if (i == 0 || cluster[k] != cluster[(size_t)allele_groups[i - 1]]) ++gene;
+        gene_of_allele[i] = gene;
+    }
+    *n_alleles = A; *n_genes = (uint64_t)(gene + 1);
+    // per file: its first insertions (allele rows, gene rows) and the records that have no row, in record order
+    struct PerFile { std::vector<int32_t> a, g; std::vector<int64_t> lost; };
+    std::vector<PerFile> per(NF);
+    parallel_for(NF, S->threads, [&](size_t f) {
+        const uint64_t r0 = S->first_rec[f], r1 = S->first_rec[f + 1];
+        size_t cap = 16;
+        while (cap < 2 * (r1 - r0) + 2) cap <<= 1;
+        std::vector<int32_t> ta(cap, -1), tg(cap, -1);
+        PerFile &P = per[f];
+        auto insert = [&](std::vector<int32_t> &t, int32_t v) {     // true: v is new
+            size_t h = ((size_t)(uint32_t)v * 0x9E3779B1u) & (cap - 1);
+            for (;; h = (h + 1) & (cap - 1)) {
+                if (t[h] == v) return false;
+                if (t[h] < 0) { t[h] = v; return true; }
+            }
+        };
+        for (uint64_t r = r0; r < r1; ++r) {
+            const int32_t grp = S->group_of[r];
+            if (grp == -1) continue;                                  // a header without a sequence
+            const int32_t row = grp >= 0 ? row_of_group[(size_t)grp] : -1;
+            if (row < 0) { P.lost.push_back((int64_t)r); continue; }   // no name, or a sequence the clustering discarded
+            if (insert(ta, row)) P.a.push_back(row);
+            if (insert(tg, gene_of_allele[row])) P.g.push_back(gene_of_allele[row]);
+        }
+    });
+    uint64_t na = 0, ng = 0, nl = 0;
+    std::vector<uint64_t> at_a(NF), at_g(NF);
+    for (uint64_t i = 0; i < NF; ++i) {
+        const size_t f = (size_t)file_order[i];
+        at_a[f] = na; na += per[f].a.size();
+        at_g[f] = ng; ng += per[f].g.size();
+        for (int64_t r : per[f].lost) lost_records[nl++] = r;
+    }
+    parallel_for(NF, S->threads, [&](size_t f) {
+        const int32_t col = genome_of_file[f];
+        std::copy(per[f].a.begin(), per[f].a.end(), a_row + at_a[f]);
+        std::fill(a_col + at_a[f], a_col + at_a[f] + per[f].a.size(), col);
+        std::copy(per[f].g.begin(), per[f].g.end(), g_row + at_g[f]);
+        std::fill(g_col + at_g[f], g_col + at_g[f] + per[f].g.size(), col);
+    });
+    *a_nnz = na; *g_nnz = ng; *n_lost = nl;
+    return PGX_OK;
+}
+
 // the allocating entry points behind their exception guards
+int pgx_fasta_feature_coo(const pgx_fasta_set *S, const int32_t *cluster, const int32_t *member, const int32_t *file_order,
+                          const int32_t *genome_of_file, int64_t *allele_groups, int32_t *gene_of_allele, uint64_t *n_alleles,
+                          uint64_t *n_genes, int32_t *a_row, int32_t *a_col, uint64_t *a_nnz, int32_t *g_row, int32_t *g_col,
+                          uint64_t *g_nnz, int64_t *lost_records, uint64_t *n_lost) {
+    return guarded("pgx_fasta_feature_coo", [&] {
+        return pgx_fasta_feature_coo_impl(S, cluster, member, file_order, genome_of_file, allele_groups, gene_of_allele, n_alleles,
+                                          n_genes, a_row, a_col, a_nnz, g_row, g_col, g_nnz, lost_records, n_lost);
+    });
+}
 int pgx_allele_order(const int32_t *cluster, const int32_t *member, uint64_t n, int64_t *out_order) {
     return guarded("pgx_allele_order", [&] { return pgx_allele_order_impl(cluster, member, n, out_order); });
 }

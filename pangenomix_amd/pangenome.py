@@ -413,6 +413,29 @@ def _lex_key(values, shorter_first):
     return ((v + 1) * scale - 1) * 32 + (31 - nd)
 
 
+class _Beside(object):
+    """A step of the pipeline that runs beside the caller's next steps on a thread of its own (the library's file
+    work releases the GIL). wait() returns when it is done and raises what it raised."""
+
+    def __init__(self, fn):
+        import threading
+        self._exc = None
+
+        def run():
+            try:
+                fn()
+            except BaseException as exc:          # handed to the thread that waits
+                self._exc = exc
+        self._thread = threading.Thread(target=run)
+        self._thread.start()
+
+    def wait(self):
+        self._thread.join()
+        exc, self._exc = self._exc, None
+        if exc is not None:
+            raise exc
+
+
 def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, cluster_type, cdhit_args,
                      fastasort_path, cluster_fn=None):
     """consolidate_seqs -> cluster_with_cdhit -> rename_genes_and_alleles -> build_genetic_feature_tables
@@ -444,14 +467,16 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         print('Note: taking the step-by-step path (%s)' % exc)   # the native ingest holds 2-3x the input in memory
         return None
     lap('ingest (parse, sha256, dedupe)')
+    beside = []           # file work in flight: it reads the set's memory, so it is waited for before the set is closed
     try:
         if not fs.simple:
             print('Note: taking the step-by-step path (%s)' % fs.why)
             return None
         # H1 (:336-405); the nr FASTA itself is written once, below, with the allele names (:524-544 rewrites it)
-        fs.write_consolidated(None, shared, missing)
+        # (the header files do not depend on the clustering and are written beside it)
+        headers_written = _Beside(lambda: fs.write_consolidated(None, shared, missing))
+        beside.append(headers_written)
         print('Headers without sequences:', fs.n_missing)
-        lap('redundant / missing headers')
         nucleotide = nr_fasta[-4:].lower() == '.fna'                           # K1/K2 (:425-450)
         params = cluster.params_from_cdhit_args(cdhit_args, 'nt' if nucleotide else 'aa')
         print('Running: libpgx greedy clustering (%s rules) -i %s -o %s -c %g -n %d' % (
@@ -459,11 +484,17 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         cl, mem, iden, strand, n_clusters = (cluster_fn or cluster.cluster_sequences)(fs.residues, fs.offsets, params)[:5]
         print('%9d  finished  %9d  clusters' % (int((cl >= 0).sum()), n_clusters))
         lap('clustering (H2D included)')
+        headers_written.wait()
+        lap('redundant / missing headers (the rest)')
         prefix = name + '_' + CLUSTER_TYPES[cluster_type]                      # H2 (:453-560)
-        fs.write_clustered(cl, mem, iden, strand, nucleotide, prefix, VARIANT_TYPES['allele'],
-                           clstr_path=nr_fasta + '.cdhit.clstr', names_path=names_tsv, nr_out_path=nr_fasta + '.tmp')
-        os.replace(nr_fasta + '.tmp', nr_fasta)
-        lap('.clstr, names, nr FASTA')
+
+        def write_outputs():
+            fs.write_clustered(cl, mem, iden, strand, nucleotide, prefix, VARIANT_TYPES['allele'],
+                               clstr_path=nr_fasta + '.cdhit.clstr', names_path=names_tsv, nr_out_path=nr_fasta + '.tmp')
+            os.replace(nr_fasta + '.tmp', nr_fasta)
+        # (the three text files and the tables below need nothing of each other: the files are written meanwhile)
+        outputs_written = _Beside(write_outputs)
+        beside.append(outputs_written)
         unclustered = np.flatnonzero(cl < 0)
         if unclustered.size:
             for h in fs.headers(fs.rep_of_group[unclustered]):
@@ -472,45 +503,31 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         print('Loadings header-allele mappings...')                            # H4 (:563-680)
         genome_order = sorted(genomes)
         print('Sorting alleles...')
-        clustered = np.flatnonzero(cl >= 0)
-        order = _native.allele_order(cl[clustered], mem[clustered])   # (= np.lexsort of the _lex_key()s above)
-        allele_groups = clustered[order]                       # groups in allele-row order
-        row_of_group = np.full(fs.n_groups, -1, dtype=np.int64)
-        row_of_group[allele_groups] = np.arange(allele_groups.size)
+        # rows of the allele table = the clustered sequences in the order of their names, genes = runs of one cluster;
+        # records in sorted(path) order, file order inside (:635); a record counts if it has a sequence (:643); a pair
+        # (row, genome) is kept where it is inserted first (:649-650) -- one pass over the parsed files in the library
+        genome_of_file = np.array([genome_order.index(g) for g in genomes], dtype=np.int64)
+        file_order = np.argsort(np.array(genome_paths, dtype=object), kind='stable')
+        t = fs.feature_coo(cl, mem, file_order, genome_of_file)
+        allele_groups = t['allele_groups']
         print('Sorting clusters...')
         c_sorted = cl[allele_groups]
         new_gene = np.ones(c_sorted.size, dtype=bool)
         new_gene[1:] = c_sorted[1:] != c_sorted[:-1]
-        gene_of_allele = np.cumsum(new_gene) - 1
         allele_order = _native.format_labels(prefix, c_sorted, mem[allele_groups], VARIANT_TYPES['allele'])
         gene_order = _native.format_labels(prefix, c_sorted[new_gene])
         print('Genomes:', len(genome_order))
         print('Clusters:', len(gene_order))
         print('Alleles:', len(allele_order))
-        # records in sorted(path) order, file order inside (:635); a record counts if it has a sequence (:643)
-        path_rank = np.empty(len(genome_paths), dtype=np.int64)
-        path_rank[np.argsort(np.array(genome_paths, dtype=object), kind='stable')] = np.arange(len(genome_paths))
-        genome_of_file = np.array([genome_order.index(g) for g in genomes], dtype=np.int64)
-        file_of = fs.file_of_record.astype(np.int64)
-        # (records are stored file after file: the stable sort by file rank is a concatenation of whole ranges)
-        starts = np.searchsorted(file_of, np.arange(len(genome_paths) + 1))
-        by_rank = np.argsort(path_rank, kind='stable')
-        recs = np.concatenate([np.arange(starts[f], starts[f + 1], dtype=np.int64) for f in by_rank]) \
-            if file_of.size else np.zeros(0, dtype=np.int64)
-        grp = fs.group_of_record[recs]
-        seen = grp != -1                                       # (-2: a sequence without a name, 'MISSING: ' below)
-        recs, grp = recs[seen], grp[seen]
-        rows = np.where(grp >= 0, row_of_group[np.maximum(grp, 0)], -1)
-        lost = np.flatnonzero(rows < 0)
-        if lost.size:
-            for h in fs.headers(recs[lost]):
+        if t['lost_records'].size:
+            for h in fs.headers(t['lost_records']):
                 print('MISSING:', h)
-        keep = rows >= 0
-        rec_allele, rec_genome = rows[keep], genome_of_file[file_of[recs[keep]]]
         print('Building binary matrix...')
-        sp_alleles = _first_occurrence_coo(rec_allele, rec_genome, len(allele_order), len(genome_order))
-        sp_genes = _first_occurrence_coo(gene_of_allele[rec_allele] if rec_allele.size else rec_allele,
-                                         rec_genome, len(gene_order), len(genome_order))
+
+        def ones_coo(row, col, shape):
+            return scipy.sparse.coo_matrix((np.ones(row.size, dtype=np.int64), (row, col)), shape=shape)
+        sp_alleles = ones_coo(t['a_row'], t['a_col'], (len(allele_order), len(genome_order)))
+        sp_genes = ones_coo(t['g_row'], t['g_col'], (len(gene_order), len(genome_order)))
         out = (sparse_utils.LightSparseDataFrame(allele_order, genome_order, sp_alleles),
                sparse_utils.LightSparseDataFrame(gene_order, genome_order, sp_genes))
         lap('tables')
@@ -528,9 +545,18 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
             except _native.PgxError as exc:       # (the tables are complete without it)
                 print('Note: no device-resident bitmap (%s)' % exc)
             lap('device-resident bitmap')
+        outputs_written.wait()
+        lap('.clstr, names, nr FASTA (the rest)')
         return out
     finally:
-        fs.close()
+        for b in beside:
+            try:
+                b.wait()
+            except BaseException:     # (reported by the wait() above unless something else failed first)
+                pass
+        # (giving back the set's memory, a GB for the benchmark's input, takes 50 ms: nobody waits for it)
+        import threading
+        threading.Thread(target=fs.close).start()
 
 
 # ---------------------------------------------------------------------------
