@@ -510,12 +510,14 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         file_order = np.argsort(np.array(genome_paths, dtype=object), kind='stable')
         t = fs.feature_coo(cl, mem, file_order, genome_of_file)
         allele_groups = t['allele_groups']
+        lap('tables: coordinates')
         print('Sorting clusters...')
         c_sorted = cl[allele_groups]
         new_gene = np.ones(c_sorted.size, dtype=bool)
         new_gene[1:] = c_sorted[1:] != c_sorted[:-1]
         allele_order = _native.format_labels(prefix, c_sorted, mem[allele_groups], VARIANT_TYPES['allele'])
         gene_order = _native.format_labels(prefix, c_sorted[new_gene])
+        lap('tables: names')
         print('Genomes:', len(genome_order))
         print('Clusters:', len(gene_order))
         print('Alleles:', len(allele_order))
@@ -530,7 +532,7 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         sp_genes = ones_coo(t['g_row'], t['g_col'], (len(gene_order), len(genome_order)))
         out = (sparse_utils.LightSparseDataFrame(allele_order, genome_order, sp_alleles),
                sparse_utils.LightSparseDataFrame(gene_order, genome_order, sp_genes))
-        lap('tables')
+        lap('tables: matrices')
         if cluster_fn is None:
             # Device-resident hand-off: the gene x genome bitmap is built on the GPU straight from the clustering
             # result (rows = cluster numbers; the curves do not depend on the row order) and stays in the context;
