@@ -1565,6 +1565,12 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
     __shared__ uint32_t taap[kNAA1 * kNAA1 + 7];
     __shared__ uint32_t abeg[kNAA1 * kNAA1 + 7];
     __shared__ uint16_t alist[CAP];
+    // the pair's residues, staged with 16-byte loads (one instruction per sequence up to 1 KB): read byte by byte from
+    // global memory, every one of the passes below waited for its own loads -- four to five memory latencies per pair,
+    // which is what a pair cost
+    constexpr uint32_t kRepCap = CAP * 3 / 2;
+    __shared__ uint4 stage1[kWideCell ? 1 : CAP / 16 + 2];
+    __shared__ uint4 stage2[kWideCell ? 1 : kRepCap / 16 + 2];
     const uint32_t lane = threadIdx.x;
     const uint32_t np = sel_count(sel);
     const int N2 = S.nt ? 256 : kNAA1 * kNAA1;
@@ -1591,10 +1597,53 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
         Cell *dg = big ? reinterpret_cast<Cell *>(gscratch + (size_t)blockIdx.x * gscratch_stride) : diag;
         // the query's 2-mer position lists (global scratch tail for oversized queries: behind 2 x cells diagonals)
         uint32_t *al_big = big ? reinterpret_cast<uint32_t *>(dg + 2 * (size_t)gscratch_cells) : nullptr;
+        const int last1 = len1 - S.kd, last2 = len2 - S.kd;
+        const bool in_lds = !kWideCell && !big && (uint32_t)len2 <= kRepCap;
+        if (in_lds) {
+            // ---- the common case, all in LDS: the query's k-mer positions as chains (head per code, next per position:
+            // one pass, no counting), the representative's k-mers walk them ----
+            const uint8_t *g1 = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(s1) & ~uintptr_t(15));
+            const uint8_t *g2 = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(s2) & ~uintptr_t(15));
+            const uint32_t sh1 = (uint32_t)(s1 - g1), sh2 = (uint32_t)(s2 - g2);
+            const uint32_t nv1 = (sh1 + (uint32_t)len1 + 15u) / 16u, nv2 = (sh2 + (uint32_t)len2 + 15u) / 16u;
+            uint4 v1[(CAP / 16 + 2 + 63) / 64], v2[(kRepCap / 16 + 2 + 63) / 64];
+#pragma unroll
+            for (uint32_t t = 0; t < sizeof(v1) / sizeof(uint4); ++t) if (lane + 64 * t < nv1) v1[t] = reinterpret_cast<const uint4 *>(g1)[lane + 64 * t];
+#pragma unroll
+            for (uint32_t t = 0; t < sizeof(v2) / sizeof(uint4); ++t) if (lane + 64 * t < nv2) v2[t] = reinterpret_cast<const uint4 *>(g2)[lane + 64 * t];
+            constexpr uint32_t kEnd = 0xFFFFu;
+            uint32_t *head = taap;
+            uint16_t *next = alist;
+            for (int i = lane; i < n_d; i += 64) diag[i] = Cell(0);
+            for (int c = lane; c < N2; c += 64) head[c] = kEnd;
+#pragma unroll
+            for (uint32_t t = 0; t < sizeof(v1) / sizeof(uint4); ++t) if (lane + 64 * t < nv1) stage1[lane + 64 * t] = v1[t];
+#pragma unroll
+            for (uint32_t t = 0; t < sizeof(v2) / sizeof(uint4); ++t) if (lane + 64 * t < nv2) stage2[lane + 64 * t] = v2[t];
+            __syncthreads();
+            const uint8_t *l1 = reinterpret_cast<const uint8_t *>(stage1) + sh1;
+            const uint8_t *l2 = reinterpret_cast<const uint8_t *>(stage2) + sh2;
+            for (int j = lane; j <= last1; j += 64) {
+                int cpx;
+                const int c = kd_code(S, l1, j, &cpx);
+                if (c >= 0) next[j] = (uint16_t)atomicExch(&head[c], (uint32_t)j);
+            }
+            __syncthreads();
+            for (int i = lane; i <= last2; i += 64) {
+                int cpx;
+                const int c = kd_code(S, l2, i, &cpx);
+                if (c < 0) continue;
+                const Cell inc = Cell(1) | (Cell((uint32_t)cpx) << kHalf);
+                for (uint32_t j = head[c]; j != kEnd; j = next[j]) {
+                    const int d = len1 - 1 + i - (int)j;
+                    if (d >= d_lo && d <= d_hi) atomicAdd(&diag[d - d_lo], inc);
+                }
+            }
+            __syncthreads();
+        } else {
         for (int i = lane; i < n_d; i += 64) dg[i] = Cell(0);
         for (int c = lane; c < N2; c += 64) taap[c] = 0u;
         __syncthreads();
-        const int last1 = len1 - S.kd, last2 = len2 - S.kd;
         for (int j = lane; j <= last1; j += 64) {
             int cpx;
             const int c = kd_code(S, s1, j, &cpx);
@@ -1629,10 +1678,12 @@ __global__ __launch_bounds__(64) void diag_kernel(DevSeqs S, const uint32_t *__r
             }
         }
         __syncthreads();
+        }
         int best_sum, bl, bc, br;
         {
             const int bw = band_width < len1 + len2 - 2 ? band_width : len1 + len2 - 2;
-            band_from_histogram(dg - d_lo, len1, len2, bw, req_aa1[k1r], cluster_thd, &best_sum, &bl, &bc, &br);
+            if (in_lds) band_from_histogram(diag - d_lo, len1, len2, bw, req_aa1[k1r], cluster_thd, &best_sum, &bl, &bc, &br);
+            else band_from_histogram(dg - d_lo, len1, len2, bw, req_aa1[k1r], cluster_thd, &best_sum, &bl, &bc, &br);
         }
         if (lane == 0) {
             uint32_t fl = F_EVAL;
