@@ -395,6 +395,73 @@ __global__ __launch_bounds__(THREADS) void words_hash_kernel(const uint8_t *__re
         if (hk[i] != kSentinel) { wcode[o + idx] = hk[i]; wmult[o + idx] = (uint16_t)hc[i]; ++idx; }
 }
 
+// Sequences of up to 512 words (most of them), one WAVE per sequence and four sequences per workgroup: no workgroup
+// barrier anywhere, 4 KB of LDS per sequence (eight waves per SIMD), one memory latency for the residues.
+//   * the residues arrive with ONE 16-byte load per lane (aligned down; up to 537 bytes) and are read from LDS;
+//   * code and count share a 32-bit slot (code << 10 | count: a code has 22 bits, a count is at most 512), so an
+//     insertion is one compare-and-swap or one add and the table is 1024 x 4 bytes;
+//   * the occupied slots are written out in slot order, 64 slots per step, compacted with a ballot.
+__global__ __launch_bounds__(256) void words_wave_kernel(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
+                                                         const uint32_t *__restrict__ len, uint32_t k0, uint32_t k1,
+                                                         int word_len, int base, int nt, uint32_t *__restrict__ wcode,
+                                                         uint16_t *__restrict__ wmult, uint32_t *__restrict__ wcnt) {
+    constexpr uint32_t SLOTS = 1024, kStage = 35;          // 35 x 16 bytes >= 15 + 512 + 10 residues
+    __shared__ uint4 table4[4][SLOTS / 4];
+    __shared__ uint4 stage[4][kStage];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t k = k0 + blockIdx.x * 4u + wv;
+    if (k >= k1) return;                                    // (wave-uniform; the waves of a workgroup share nothing)
+    const uint64_t o = off[k];
+    const uint32_t L = len[k], nw = L - (uint32_t)word_len + 1u;
+    const uint8_t *s = res + o;
+    const uint8_t *g = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(s) & ~uintptr_t(15));
+    const uint32_t sh = (uint32_t)(s - g), nv = (sh + L + 15u) / 16u;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (lane < nv && lane < kStage) v = reinterpret_cast<const uint4 *>(g)[lane];
+    uint32_t *tb = reinterpret_cast<uint32_t *>(table4[wv]);
+#pragma unroll
+    for (uint32_t t = 0; t < SLOTS / 4 / 64; ++t) table4[wv][lane + 64u * t] = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
+    if (lane < kStage) stage[wv][lane] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint8_t *l = reinterpret_cast<const uint8_t *>(stage[wv]) + sh;
+    for (uint32_t i = lane; i < nw; i += 64u) {
+        uint32_t key = 0;
+        bool bad = false;
+        for (int t = 0; t < word_len; ++t) { const uint32_t r = l[i + t]; key = key * (uint32_t)base + r; bad |= r >= (uint32_t)base; }
+        if (nt && bad) continue;                          // words containing N are skipped
+        uint32_t slot = (key * 0x9E3779B1u) >> 7 & (SLOTS - 1u);
+        for (;;) {                                         // (at most half the slots are ever taken)
+            const uint32_t cur = tb[slot];
+            if (cur != kSentinel && (cur >> 10) == key) { atomicAdd(&tb[slot], 1u); break; }
+            if (cur == kSentinel) {
+                const uint32_t was = atomicCAS(&tb[slot], kSentinel, key << 10 | 1u);
+                if (was == kSentinel) break;
+                if ((was >> 10) == key) { atomicAdd(&tb[slot], 1u); break; }
+            }
+            slot = (slot + 1u) & (SLOTS - 1u);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t n_out = 0;
+#pragma unroll 4
+    for (uint32_t r = 0; r < SLOTS / 64u; ++r) {
+        const uint32_t e = tb[r * 64u + lane];
+        const bool occ = e != kSentinel;
+        const unsigned long long m = __ballot(occ);
+        if (occ) {
+            const uint32_t at = n_out + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            wcode[o + at] = e >> 10;
+            wmult[o + at] = (uint16_t)(e & 1023u);
+        }
+        n_out += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) wcnt[k] = n_out;
+}
+
 // Sequences of more than 32768 words (rare: a handful of giant proteins): the same open-addressing table in a GLOBAL
 // scratch region of the workgroup (`slots` a power of two >= 2 x words, keys and counts), one workgroup per sequence.
 __global__ __launch_bounds__(1024) void words_huge_kernel(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
@@ -2671,7 +2738,11 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             if ((rc = launch_words<32768, 1024>(ctx, st, r8, o64, l32, o + k32, o + k8, wl, base, nt, wc, wm, wn))) return rc;
             if ((rc = launch_words<8192, 1024>(ctx, st, r8, o64, l32, o + k8, o + k2, wl, base, nt, wc, wm, wn))) return rc;
             if ((rc = launch_words_hash<2048, 256>(ctx, st, r8, o64, l32, o + k2, o + k5, wl, base, nt, wc, wm, wn))) return rc;
-            if ((rc = launch_words_hash<512, 128>(ctx, st, r8, o64, l32, o + k5, o + n, wl, base, nt, wc, wm, wn))) return rc;
+            if (n > k5) {
+                ProfScope prof(ctx, "words_kernel", st);
+                words_wave_kernel<<<(n - k5 + 3) / 4, 256, 0, st>>>(r8, o64, l32, o + k5, o + n, wl, base, nt, wc, wm, wn);
+                LAUNCH_CHECK();
+            }
         }
     }
     DevSeqs DS{d_res.as<uint8_t>(), d_off.as<uint64_t>(), d_len.as<uint32_t>(),
