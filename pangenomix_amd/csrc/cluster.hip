@@ -401,11 +401,14 @@ __global__ __launch_bounds__(THREADS) void words_hash_kernel(const uint8_t *__re
 //   * code and count share a 32-bit slot (code << 10 | count: a code has 22 bits, a count is at most 512), so an
 //     insertion is one compare-and-swap or one add and the table is 1024 x 4 bytes;
 //   * the occupied slots are written out in slot order, 64 slots per step, compacted with a ballot.
+// SLOTS = 2048 takes the sequences of up to 1023 words the same way (a count still fits ten bits; 8 KB per sequence).
+template <uint32_t SLOTS>
 __global__ __launch_bounds__(256) void words_wave_kernel(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
                                                          const uint32_t *__restrict__ len, uint32_t k0, uint32_t k1,
                                                          int word_len, int base, int nt, uint32_t *__restrict__ wcode,
                                                          uint16_t *__restrict__ wmult, uint32_t *__restrict__ wcnt) {
-    constexpr uint32_t SLOTS = 1024, kStage = 35;          // 35 x 16 bytes >= 15 + 512 + 10 residues
+    constexpr uint32_t kStage = (15 + SLOTS / 2 + 10 + 15) / 16 + 1;   // 16-byte pieces of the longest sequence, shifted
+    constexpr uint32_t kLoads = (kStage + 63) / 64;
     __shared__ uint4 table4[4][SLOTS / 4];
     __shared__ uint4 stage[4][kStage];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -416,12 +419,17 @@ __global__ __launch_bounds__(256) void words_wave_kernel(const uint8_t *__restri
     const uint8_t *s = res + o;
     const uint8_t *g = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(s) & ~uintptr_t(15));
     const uint32_t sh = (uint32_t)(s - g), nv = (sh + L + 15u) / 16u;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (lane < nv && lane < kStage) v = reinterpret_cast<const uint4 *>(g)[lane];
+    uint4 v[kLoads];
+#pragma unroll
+    for (uint32_t t = 0; t < kLoads; ++t) {
+        v[t] = make_uint4(0, 0, 0, 0);
+        if (lane + 64u * t < nv && lane + 64u * t < kStage) v[t] = reinterpret_cast<const uint4 *>(g)[lane + 64u * t];
+    }
     uint32_t *tb = reinterpret_cast<uint32_t *>(table4[wv]);
 #pragma unroll
     for (uint32_t t = 0; t < SLOTS / 4 / 64; ++t) table4[wv][lane + 64u * t] = make_uint4(kSentinel, kSentinel, kSentinel, kSentinel);
-    if (lane < kStage) stage[wv][lane] = v;
+#pragma unroll
+    for (uint32_t t = 0; t < kLoads; ++t) if (lane + 64u * t < kStage) stage[wv][lane + 64u * t] = v[t];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2716,7 +2724,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                                                    [&](uint32_t L) { return L - wl + 1 > cap; }) - h_len.begin());
         };
         const uint32_t k32 = first_with_words_le(32768), k8 = first_with_words_le(8192),
-                       k2 = first_with_words_le(2048), k5 = first_with_words_le(512);
+                       k2 = first_with_words_le(2048), k1k = first_with_words_le(1023), k5 = first_with_words_le(512);
         int rc;
         uint8_t *r8 = d_res.as<uint8_t>(); uint64_t *o64 = d_off.as<uint64_t>(); uint32_t *l32 = d_len.as<uint32_t>();
         uint32_t *wc = d_wcode.as<uint32_t>(); uint16_t *wm = d_wmult.as<uint16_t>(); uint32_t *wn = d_wcnt.as<uint32_t>();
@@ -2737,10 +2745,15 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             }
             if ((rc = launch_words<32768, 1024>(ctx, st, r8, o64, l32, o + k32, o + k8, wl, base, nt, wc, wm, wn))) return rc;
             if ((rc = launch_words<8192, 1024>(ctx, st, r8, o64, l32, o + k8, o + k2, wl, base, nt, wc, wm, wn))) return rc;
-            if ((rc = launch_words_hash<2048, 256>(ctx, st, r8, o64, l32, o + k2, o + k5, wl, base, nt, wc, wm, wn))) return rc;
+            if ((rc = launch_words_hash<2048, 256>(ctx, st, r8, o64, l32, o + k2, o + k1k, wl, base, nt, wc, wm, wn))) return rc;
+            if (k5 > k1k) {
+                ProfScope prof(ctx, "words_kernel", st);
+                words_wave_kernel<2048><<<(k5 - k1k + 3) / 4, 256, 0, st>>>(r8, o64, l32, o + k1k, o + k5, wl, base, nt, wc, wm, wn);
+                LAUNCH_CHECK();
+            }
             if (n > k5) {
                 ProfScope prof(ctx, "words_kernel", st);
-                words_wave_kernel<<<(n - k5 + 3) / 4, 256, 0, st>>>(r8, o64, l32, o + k5, o + n, wl, base, nt, wc, wm, wn);
+                words_wave_kernel<1024><<<(n - k5 + 3) / 4, 256, 0, st>>>(r8, o64, l32, o + k5, o + n, wl, base, nt, wc, wm, wn);
                 LAUNCH_CHECK();
             }
         }
