@@ -235,7 +235,12 @@ typedef struct pgx_cluster_stats {
  *   out_cluster[i]  cluster number in order of representative creation, -1 = discarded
  *   out_member[i]   index inside the cluster = .clstr member number (0 = representative)
  *   out_identity[i] matches / query length as float (0 for representatives)
- *   out_strand[i]   0 '+', 1 '-' (nucleotide, both_strands; may be NULL) */
+ *   out_strand[i]   0 '+', 1 '-' (nucleotide, both_strands; may be NULL)
+ *   stats           may be NULL. The counters are those of the SEQUENTIAL rule, which looks up every word of every
+ *                   sequence in the whole table; with stats the library does all of those look-ups so that its
+ *                   counters equal that rule's. Without, the passes over a window's new representatives leave out the
+ *                   members that cannot gain from them (final ones; those whose best candidate no new representative
+ *                   can precede). The clusters, member numbers, identities and strands are the same either way. */
 int pgx_cluster_greedy(pgx_ctx *ctx, const uint8_t *residues, const uint64_t *offsets, uint32_t n,
                        const pgx_cluster_params *params, int32_t *out_cluster, int32_t *out_member,
                        float *out_identity, uint8_t *out_strand, uint32_t *out_n_clusters,

@@ -427,7 +427,9 @@ class Context(object):
         return pan, core
 
     # -- K1/K2 ---------------------------------------------------------------
-    def cluster_greedy(self, residues, offsets, params):
+    def cluster_greedy(self, residues, offsets, params, want_stats=True):
+        """want_stats=False: no work counters (stats is None in the result) and the library leaves out the look-ups
+        that only the counters need (pgx.h); the clustering is the same."""
         residues = np.ascontiguousarray(residues, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
@@ -439,11 +441,11 @@ class Context(object):
         stats = ClusterStats()
         check(lib().pgx_cluster_greedy(self._h, _ptr(residues), _ptr(offsets), n, C.byref(params),
                                        _ptr(out_cluster), _ptr(out_member), _ptr(out_identity),
-                                       _ptr(out_strand), C.byref(n_clusters), C.byref(stats)))
-        return out_cluster, out_member, out_identity, out_strand, int(n_clusters.value), stats.as_dict()
+                                       _ptr(out_strand), C.byref(n_clusters), C.byref(stats) if want_stats else None))
+        return out_cluster, out_member, out_identity, out_strand, int(n_clusters.value), stats.as_dict() if want_stats else None
 
 
-    def cluster_greedy_dev(self, d_residues, d_offsets, n, total_bytes, params, stream=0):
+    def cluster_greedy_dev(self, d_residues, d_offsets, n, total_bytes, params, stream=0, want_stats=True):
         """Sequences resident in HBM (raw device addresses); outputs are host arrays."""
         out_cluster = np.empty(n, dtype=np.int32)
         out_member = np.empty(n, dtype=np.int32)
@@ -454,8 +456,8 @@ class Context(object):
         check(lib().pgx_cluster_greedy_dev(self._h, d_residues, d_offsets, int(n), int(total_bytes),
                                            C.byref(params), _ptr(out_cluster), _ptr(out_member),
                                            _ptr(out_identity), _ptr(out_strand), C.byref(n_clusters),
-                                           C.byref(stats), stream))
-        return out_cluster, out_member, out_identity, out_strand, int(n_clusters.value), stats.as_dict()
+                                           C.byref(stats) if want_stats else None, stream))
+        return out_cluster, out_member, out_identity, out_strand, int(n_clusters.value), stats.as_dict() if want_stats else None
 
 
 class FastaSet(object):

@@ -689,6 +689,7 @@ struct FilterArgs {
     const uint32_t *qlist, *d_nq;
     uint8_t *mark;
     uint32_t count_visits;
+    uint32_t lean;            // the caller wants no work counters: members that cannot gain from a pass are not walked
 };
 
 // multiplicity of `code` in the word list of sequence r (present by construction of the index);
@@ -1059,6 +1060,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT ? 1 : 5,
         const uint32_t thr = t0 > 1 ? (uint32_t)t0 : 1u;
         const uint64_t o = me.o;
         const uint32_t nw = me.nw;
+        if (NEWONLY && A.lean) {
+            // Without the counters of the sequential rule a pass over a round's new representatives owes a member
+            // only the candidates that can still beat its best key (strand | smallest shared word | representative:
+            // what `emit` lets through). A final member has none. A member that holds a best key can only be beaten
+            // through a word whose code does not exceed the key's -- in a family that is the member's one or two
+            // smallest words -- so its codes are scanned (a stream) and the round's map is asked about those few; only
+            // if one of them is marked is the member walked. [More than half of the members have their
+            // representative after the pass over the whole index: the round passes walked them all for the counters.]
+            if (count_only) continue;
+            if (me.best != kNoBest) {
+                const bool best_rc = (me.best >> 63) != 0ull;
+                if (rstrand && !best_rc) continue;                    // a reverse-strand candidate never beats a forward one
+                if (rstrand == best_rc) {
+                    const uint32_t mb = (uint32_t)(me.best >> 32) & 0x7FFFFFFFu;
+                    bool any = false;
+                    for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+                        const uint32_t w = w0 + lane;
+                        if (w >= nw) continue;
+                        const uint32_t c = S.wcode[o + w];
+                        if (c <= mb) any |= ((A.newbits[c >> 3] >> ((c & 7u) * kSegs + seg)) & 1u) != 0u;
+                    }
+                    if (!__ballot(any)) continue;
+                }
+            }
+        }
         uint32_t visits = 0;
         bool hot = false, full = false;
         Marked marked{0u, 0u, 0u, false};
@@ -2938,6 +2964,7 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
         FA.pairs = pairsW; FA.n_pairs = dc + C_NW; FA.pair_cap = pair_cap;
         FA.visits = d_visits.as<unsigned long long>(); FA.rc_visits = d_rcvis_p; FA.err = dc + C_ERR;
         FA.qlist = nullptr; FA.d_nq = nullptr; FA.mark = nullptr; FA.count_visits = 1u;
+        FA.lean = stats == nullptr && !std::getenv("PGX_NO_LEAN") ? 1u : 0u;
 
         window_init_kernel<<<(window_cap + 255) / 256, 256, 0, st>>>(dc, d_best, both ? d_rcvis_p : nullptr, d_done, window_cap);
         if (!flush_at.empty() && next_flush > 0)

@@ -481,7 +481,10 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         params = cluster.params_from_cdhit_args(cdhit_args, 'nt' if nucleotide else 'aa')
         print('Running: libpgx greedy clustering (%s rules) -i %s -o %s -c %g -n %d' % (
             'cd-hit-est' if nucleotide else 'cd-hit', nr_fasta, nr_fasta + '.cdhit', params.identity, params.word_len))
-        cl, mem, iden, strand, n_clusters = (cluster_fn or cluster.cluster_sequences)(fs.residues, fs.offsets, params)[:5]
+        if cluster_fn is None:      # (nobody reads the work counters here: the library leaves out what only they need)
+            cl, mem, iden, strand, n_clusters = cluster.cluster_sequences(fs.residues, fs.offsets, params, want_stats=False)[:5]
+        else:
+            cl, mem, iden, strand, n_clusters = cluster_fn(fs.residues, fs.offsets, params)[:5]
         print('%9d  finished  %9d  clusters' % (int((cl >= 0).sum()), n_clusters))
         lap('clustering (H2D included)')
         headers_written.wait()

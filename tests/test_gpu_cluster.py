@@ -581,3 +581,59 @@ def test_whole_noncoding_output_equals_the_step_by_step_path_fed_by_the_oracle(t
             assert_same_npz(str(outs['gpu'] / f), str(outs['ref'] / f))
         else:
             assert filecmp.cmp(str(outs['gpu'] / f), str(outs['ref'] / f), shallow=False), f
+
+
+def assert_same_outputs(lean, full, tag=''):
+    """A call without work counters against one with them: the four output arrays and the cluster count."""
+    assert lean[5] is None and full[5] is not None
+    assert lean[4] == full[4], tag
+    for i, what in enumerate(('cluster', 'member', 'identity', 'strand')):
+        np.testing.assert_array_equal(lean[i], full[i], err_msg='%s %s' % (what, tag))
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_without_counters_randomized_sets_cluster_the_same(seed, gpu_ctx):
+    """stats = NULL (want_stats=False): the passes over a window's new representatives leave out the members that
+    cannot gain from them -- final members, members whose best key no new representative can precede (pgx.h). The
+    result must not change: the randomized protein and nucleotide sets of the oracle tests above, several window
+    sizes, both strands."""
+    rng = np.random.default_rng(7000 + seed)
+    if seed % 3 < 2:
+        c = float(rng.choice([0.7, 0.8, 0.9, 0.95, 1.0]))
+        seqs = _random_families(rng, AA_LETTERS, int(rng.integers(5, 70)), int(rng.integers(1, 40)),
+                                int(rng.choice([12, 40, 120])), int(rng.choice([130, 400, 900])))
+        p = params(**{'-c': c, '-n': int(rng.choice([5, 4, 3])) if c < 0.97 else 5})
+        p.batch_size = int(rng.choice([0, 64, 128, 1024]))
+    else:
+        c = float(rng.choice([0.8, 0.9, 0.95]))
+        seqs = _random_families(rng, 'ACGT', int(rng.integers(4, 30)), int(rng.integers(1, 25)),
+                                int(rng.choice([20, 60])), int(rng.choice([150, 500])))
+        p = nt_params(**{'-c': c, '-n': int(rng.choice([8, 10])) if c >= 0.9 else 6, '-r': int(seed % 2)})
+        p.batch_size = int(rng.choice([0, 64, 256]))
+    res, off = pack(seqs)
+    full = gpu_ctx.cluster_greedy(res, off, p)
+    assert_same_outputs(gpu_ctx.cluster_greedy(res, off, p, want_stats=False), full, 'seed %d' % seed)
+    if seed % 3 < 2:
+        assert_same(full, oracle.cluster_greedy(res, off, p))
+
+
+@pytest.mark.parametrize('window', [64, 1024, 0])
+def test_without_counters_synthetic_genomes_cluster_the_same(window, gpu_ctx):
+    ps = synth.ProteinSet(30, 500, 800, 150, 77)
+    res, off, _ = ps.nr_arrays()
+    p = params()
+    p.batch_size = window
+    assert_same_outputs(gpu_ctx.cluster_greedy(res, off, p, want_stats=False), gpu_ctx.cluster_greedy(res, off, p))
+    res, off, _ = synth.noncoding_set(n_genomes=120, seed=9)
+    p = nt_params()
+    p.batch_size = window if window != 1024 else 256
+    assert_same_outputs(gpu_ctx.cluster_greedy(res, off, p, want_stats=False), gpu_ctx.cluster_greedy(res, off, p), 'nt')
+
+
+@pytest.mark.slow
+def test_without_counters_cfg3s_clusters_the_same(gpu_ctx):
+    """The benchmark workload: the call bench.py times (no counters) against the instrumented call, which
+    test_cfg3s_full_size_parity pins to the oracle."""
+    res, off, _ = synth.protein_set('cfg-3s').nr_arrays()
+    p = params()
+    assert_same_outputs(gpu_ctx.cluster_greedy(res, off, p, want_stats=False), gpu_ctx.cluster_greedy(res, off, p))

@@ -17,7 +17,7 @@ from test_gpu_cluster import assert_same, assert_same_nt, nt_params
 pytestmark = pytest.mark.gpu
 
 
-def run_virtual_ranks(res, off, p, world, expect_errors=False):
+def run_virtual_ranks(res, off, p, world, expect_errors=False, want_stats=True):
     import torch
     torch.cuda.init()
     dev = torch.device('cuda', 0)
@@ -39,7 +39,7 @@ def run_virtual_ranks(res, off, p, world, expect_errors=False):
         ctx = _native.Context(0)
         try:
             sp, keep = cluster.shard_params(p, rank, world, sends[rank], recvs[rank], all_gather)
-            results[rank] = ctx.cluster_greedy(res, off, sp)
+            results[rank] = ctx.cluster_greedy(res, off, sp, want_stats=want_stats)
             del keep
         except Exception as exc:                    # a failing rank must not leave the others at the barrier
             errors.append((rank, exc))
@@ -259,3 +259,18 @@ def test_edge_cases_on_virtual_ranks():
     results = run_virtual_ranks(res, off, params(), 2)
     assert_replicated(results)
     assert_same(fold(results), oracle.cluster_greedy(res, off, params()))
+
+
+def test_without_counters_on_virtual_ranks_clusters_the_same(gpu_ctx):
+    """stats = NULL in the record-sharded mode: every rank leaves out the members that cannot gain from a pass over the
+    new representatives (a function of the replicated best keys), the exchanges stay in step, and every rank returns
+    the clusters of the single-process call with counters."""
+    res, off, _ = synth.protein_set('small').nr_arrays()
+    p = params()
+    whole = gpu_ctx.cluster_greedy(res, off, p)
+    results = run_virtual_ranks(res, off, p, 2, want_stats=False)
+    for r in results:
+        assert r[5] is None and r[4] == whole[4]
+        np.testing.assert_array_equal(r[0], whole[0])
+        np.testing.assert_array_equal(r[1], whole[1])
+    np.testing.assert_array_equal(np.maximum(results[0][2], results[1][2]), whole[2])    # identities are partial per rank
