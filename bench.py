@@ -495,8 +495,8 @@ def main():
                               'align_kernel': 'ceil(5 A / 8): residues of the aligned representatives (SURVEY 8d)',
                               'diag_kernel': 'ceil(5 A / 8) (SURVEY 8d has no term of its own for the diagonal test)'}[dom],
                     'implementation_traffic_model': {
-                        'filter line reads (the first 64-byte half of a code\'s 128-byte line per query word in the pass over '
-                        'the whole index; the second half only for lists of more than 11 entries)':
+                        'filter line reads (the first 64-byte piece of a code\'s 256-byte line per query word in the pass over '
+                        'the whole index; the further pieces only for lists of more than 11, 27, 43 entries)':
                             64 * st['sum_len_queries'], 'note': 'what the layout moves, not algorithmic work'}}
         roofline_pc = {'bound': 'l2', 'kernel': 'pan_core_sweep_kernel', 'achieved': pc_gbs, 'peak': L2_PEAK_GBS,
                        'unit': 'GB/s', 'frac': pc_gbs / L2_PEAK_GBS, 'frac_of_hbm_peak': pc_gbs / HBM_PEAK_GBS,

@@ -12,7 +12,7 @@
 // accepted representatives r < q (r = position in the sorted order = creation order).
 //
 // The word table of the sequential rule is kept on the device for the whole call as an INVERTED
-// INDEX, one 128-byte line per word code (list length + first 27 entries; longer lists continue in a
+// INDEX, one 256-byte line per word code (list length + first 59 entries; longer lists continue in a
 // pool), appended to whenever representatives are confirmed. The short-word filter is QUERY-MAJOR:
 // one wave per query walks the lines of the query's words, so a query touches exactly the posting
 // entries the sequential rule visits.
@@ -527,32 +527,34 @@ __global__ __launch_bounds__(1024) void words_huge_kernel(const uint8_t *__restr
 }
 
 // ----------------------------------------------------------------------------------------
-// the word index: one 64-byte line per word code, appended to when representatives are created
+// the word index: one 256-byte line per word code, appended to when representatives are created
 // ----------------------------------------------------------------------------------------
 // The structure the sequential rule itself walks (its "word table": per word the representatives
 // that have it), kept for the whole call and grown in place:
-//   line[code] = { len, ovf, round, pending, e[27] }   (one 128-byte line in two 64-byte halves: ONE memory transaction
-//                gives a query the list's length and its first 11 entries; the second half -- entries 11..26, the same
-//                L2 line -- is read only when a list reaches it. [64-byte lines with 11 entries until round 3: a
-//                4000-genome index has 25 entries per list, and the 14 in the overflow pool cost a 6-step search each.]
+//   line[code] = { len, ovf, round, pending, e[59] }   (one 256-byte line in four 64-byte pieces: ONE memory transaction
+//                gives a query the list's length and its first 11 entries; the further pieces -- 16 entries each --
+//                are read only when a list reaches them. [64-byte lines with 11 entries until round 3, then 128 bytes
+//                with 27: a 4000-genome index has 28 entries per list on average, and what is in the overflow pool
+//                costs a 6-step search per entry; 128 -> 256 bytes: cfg-4 1117 -> 1079 ms, cfg-3s unchanged.]
 //   entry      = sorted sequence index of the representative (low bits) | min(multiplicity of the word in
 //                it, field maximum) above them; the field maximum means "look it up in its word list"
-//   overflow   = entries 27.. live in pool[ovf + 1 ..], a contiguous array of capacity pool[ovf]
+//   overflow   = entries 59.. live in pool[ovf + 1 ..], a contiguous array of capacity pool[ovf]
 //                that is re-allocated with twice the need when it fills (bump allocation)
 //   round      = epoch << 32 | ~len_prev: the latest append round that touched the list and the list's
 //                length before that round, so that a pass can visit exactly the entries a round added (new
 //                representatives of the window). One 64-bit atomicMax per appended entry maintains it:
 //                a newer round beats an older one, and within a round the smallest position wins.
 // Entries keep no order (candidates are ordered by an explicit key).
-constexpr uint32_t kInline = 27;     // entries in the line
+constexpr uint32_t kLineBytes = 256;
+constexpr uint32_t kInline = (kLineBytes - 20) / 4;   // entries in the line (59)
 constexpr uint32_t kInlineA = 11;    // ... of which in its first 64 bytes
-struct __attribute__((aligned(128))) IndexLine {
+struct __attribute__((aligned(kLineBytes))) IndexLine {
     uint32_t len, ovf;
     unsigned long long round;
     uint32_t pending;
     uint32_t e[kInline];
 };
-static_assert(sizeof(IndexLine) == 128, "one line per word code: two 64-byte halves");
+static_assert(sizeof(IndexLine) == kLineBytes && (kInline - kInlineA) % 16 == 0, "one line per word code: 64-byte pieces");
 __device__ __forceinline__ uint32_t line_len_prev(const IndexLine &L) { return ~(uint32_t)L.round; }
 
 // Appending the representatives list[*d_lo .. *d_hi) as round `epoch`. 94 % of the lists a protein query meets
@@ -831,17 +833,17 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
                     if (idx < hi_in) entry_visit(e, code, mq);
                 }
             }
-            // the second half of the line (entries 11 .. 26): read only when some lane's list reaches it -- the same
-            // 128-byte line, an L2 hit -- and walked the same way. [With 11 entries per line a 4000-genome index
-            // (25 entries per list) kept 14 of them in the overflow pool, whose walk costs a 6-step search per entry.]
-            if (__ballot(hi > kInlineA)) {
+            // (the further 64-byte pieces of the line, 16 entries each: a piece is read when some lane's list reaches it)
+            constexpr uint32_t kB = 16;
+            for (uint32_t piece = 0; piece < (kInline - kInlineA) / kB; ++piece) {    // (a loop: three copies of the walk do not pay)
+                const uint32_t first = kInlineA + piece * kB;
+                if (!__ballot(hi > first)) break;
                 uint4 h0 = make_uint4(0u, 0u, 0u, 0u), h1 = h0, h2 = h0, h3 = h0;
-                if (hi > kInlineA) {
-                    const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + code);
-                    h0 = lp[4]; h1 = lp[5]; h2 = lp[6]; h3 = lp[7];
+                if (hi > first) {
+                    const uint4 *lp = reinterpret_cast<const uint4 *>(A.lines + code) + 4u * (piece + 1u);
+                    h0 = lp[0]; h1 = lp[1]; h2 = lp[2]; h3 = lp[3];
                 }
-                constexpr uint32_t kB = kInline - kInlineA;   // 16
-                const uint32_t hi_b = hi > kInlineA ? (hi < kInline ? hi : kInline) - kInlineA : 0u;
+                const uint32_t hi_b = hi > first ? (hi < first + kB ? hi - first : kB) : 0u;
                 const uint32_t entsb[kB] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
 #pragma unroll
                 for (uint32_t t = 0; t < kB; ++t)     // (no rotation here: what a family shares sits at the front of its lists)
@@ -849,7 +851,7 @@ __device__ __forceinline__ void filter_walk(const DevSeqs &S, const FilterArgs &
             }
         } else {
         // A round's entries: a range of the line that starts anywhere, one or two entries as a rule. They are read
-        // where they are (the line's header has just been fetched: L2 hits) instead of holding the line's 27 entries in
+        // where they are (the line's header has just been fetched: L2 hits) instead of holding the line's entries in
         // registers and picking by select chains.
         (void)n_in;
         const uint32_t hi_l = hi < kInline ? hi : kInline;
