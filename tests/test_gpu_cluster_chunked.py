@@ -94,3 +94,21 @@ def test_flushes_on_virtual_ranks(monkeypatch):
     results = run_virtual_ranks(res, off, pc, 2)
     assert_replicated(results)
     assert_same(fold(results), oracle.cluster_greedy(res, off, pc))
+
+
+@pytest.mark.parametrize('window', [0, 256])
+def test_flushes_without_counters_cluster_the_same(window, gpu_ctx):
+    """stats = NULL together with flush positions: the sweeps run no pass over new representatives, the windows between
+    them do and leave out the members that cannot gain from it -- the same clusters as the call with counters."""
+    ps = synth.ProteinSet(30, 500, 800, 150, 77)
+    res, off, _ = ps.nr_arrays()
+    p = params()
+    p.batch_size = window
+    n = off.size - 1
+    for bd in ([n // 3], [n // 10, n // 4, n // 2]):
+        pc, keep = cluster.with_chunk_boundaries(p, bd)
+        full = gpu_ctx.cluster_greedy(res, off, pc)
+        lean = gpu_ctx.cluster_greedy(res, off, pc, want_stats=False)
+        assert lean[5] is None and lean[4] == full[4]
+        for i in range(4):
+            np.testing.assert_array_equal(lean[i], full[i])
