@@ -1899,6 +1899,7 @@ __device__ int band_align_wave(const uint8_t *__restrict__ s1, const uint8_t *__
 // len1 + len2 <= slot - 96 is handled here (both sequences, 6-padded, fit the slot); the rest, and bands over 32
 // diagonals, are counted in *n_wide and left to align_kernel.
 constexpr int kA16MaxSlot = 4096;
+constexpr int kA16BigSlot = 8192;   // second pass over what the 4 KB slots left (one workgroup per CU: only for those pairs)
 constexpr int kScaleShift = 14;
 
 __device__ __forceinline__ int dpp_row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); }
@@ -1922,7 +1923,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
                                                      Pair *__restrict__ pairs, PairSel sel,
                                                      const int32_t *__restrict__ req_aa1, double cluster_thd,
                                                      uint32_t b0, unsigned long long *__restrict__ best,
-                                                     uint32_t key_flag, uint32_t *__restrict__ n_wide) {
+                                                     uint32_t key_flag, uint32_t *__restrict__ n_wide, uint32_t second_pass) {
     // substitution score + centre bonus in key form (value * 4 + 2, see the interior rows) and the
     // identity bit, one 8-byte entry per residue pair and bonus class
     __shared__ int2 tab[4][kNAA1 * kNAA1];
@@ -1931,6 +1932,9 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
     __builtin_amdgcn_s_setprio(3);
     const uint32_t n = sel_count(sel);
     if (blockIdx.x * 16u >= n) return;   // (a round with few pairs: most workgroups have none; 50 us of table set-up otherwise)
+    // second_pass: the 8 KB-slot instantiation, launched behind the window's own for the pairs that one left (windows of
+    // sequences beyond 2,000 residues); it counts nothing and leaves at once when nothing was left
+    if (second_pass && *n_wide == 0u) return;
     for (int c = threadIdx.x; c < 4 * kNAA1 * kNAA1; c += 256) {
         const int cc = c % (kNAA1 * kNAA1);
         const int s = S.nt ? (cc / kNAA1 == cc % kNAA1 ? 2 : -2) : (int)kBlosum62_dev[cc];
@@ -1959,7 +1963,7 @@ __global__ __launch_bounds__(256) void align16_kernel(DevSeqs S, const uint32_t 
             fast = (pr.flags & (F_DIAG_PASS | F_BAND_OK | F_TOO_BIG | F_ALIGNED)) == (F_DIAG_PASS | F_BAND_OK);
             if (fast && pair_is_wide(len1, len2, pr.band_left, pr.band_right, kA16Slot - 96)) {
                 fast = false;
-                if (gl == 0) atomicAdd(n_wide, 1u);      // left to align_kernel
+                if (gl == 0 && !second_pass) atomicAdd(n_wide, 1u);      // left to the second pass / align_kernel
             }
         }
         const int bl = pr.band_left, bw = fast ? pr.band_right - pr.band_left + 1 : 0;
@@ -2997,9 +3001,16 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 ProfScope prof(ctx, "align_kernel", st);
                 auto kern = a16_slot == 1024 ? align16_kernel<1024> : (a16_slot == 1536 ? align16_kernel<1536> : (a16_slot == 2048 ? align16_kernel<2048>
                             : (a16_slot == 3072 ? align16_kernel<3072> : align16_kernel<kA16MaxSlot>)));
-                kern<<<ag, 256, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, dc + C_WIDE);
+                kern<<<ag, 256, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, dc + C_WIDE, 0u);
+                // a window whose longest query does not fit the 4 KB slots twice over: the pairs left get 8 KB slots (the
+                // general aligner computes a cell per lane every OTHER step, one pair per wave: 1.6 ms for the first
+                // window of cfg-3s, whose longest sequences are 2,101 residues)
+                const bool big_pass = a16_slot == kA16MaxSlot && two_len > kA16MaxSlot - 96;
+                if (big_pass)
+                    align16_kernel<kA16BigSlot><<<ag, 256, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr,
+                                                                    0u, dc + C_WIDE, 1u);
                 align_kernel<<<grid_hint ? std::min(align_grid, (grid_hint + 3) / 4) : align_grid, 256, 0, st>>>(
-                    DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, 1, a16_slot - 96, dc + C_WIDE);
+                    DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, 1, (big_pass ? kA16BigSlot : a16_slot) - 96, dc + C_WIDE);
             }
             LAUNCH_CHECK();
             return PGX_OK;
