@@ -2983,6 +2983,13 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             for (uint32_t q = 0; q < nb; ++q) status[q] = cluster_of[b0 + q] >= 0 ? ST_ABSENT : ST_OPEN;
             return PGX_OK;
         };
+        // Can a pair of the evaluation at hand fall outside the 16-lane aligner's slots? Its band cannot when the band
+        // width is at most 32; its lengths can when the candidates are OLDER representatives (the pass over the whole
+        // index: any length) or when the window's own longest pair exceeds the largest slot. Every other evaluation
+        // pairs members of this window with each other -- two sequences no longer than the window's first, which is
+        // what the slot was sized for -- and does not launch the general aligner at all (an empty launch is ≈ 11 us of
+        // stream time, 105 of them per step on cfg-3s).
+        bool older_reps = false;
         // diag + align of a selection of pair records, enqueued on the stream
         auto evaluate = [&](Pair *pairs, const PairSel &sel, unsigned long long *best_arr, uint32_t grid_hint) -> int {
             const uint32_t dg = grid_hint ? std::min(diag_grid, grid_hint) : diag_grid;
@@ -3006,11 +3013,13 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
                 // general aligner computes a cell per lane every OTHER step, one pair per wave: 1.6 ms for the first
                 // window of cfg-3s, whose longest sequences are 2,101 residues)
                 const bool big_pass = a16_slot == kA16MaxSlot && two_len > kA16MaxSlot - 96;
+                const bool may_be_wide = older_reps || two_len > a16_slot - 96 || P->band_width > 32;
                 if (big_pass)
                     align16_kernel<kA16BigSlot><<<ag, 256, 0, st>>>(DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr,
                                                                     0u, dc + C_WIDE, 1u);
-                align_kernel<<<grid_hint ? std::min(align_grid, (grid_hint + 3) / 4) : align_grid, 256, 0, st>>>(
-                    DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, 1, (big_pass ? kA16BigSlot : a16_slot) - 96, dc + C_WIDE);
+                if (may_be_wide)
+                    align_kernel<<<grid_hint ? std::min(align_grid, (grid_hint + 3) / 4) : align_grid, 256, 0, st>>>(
+                        DS, nullptr, pairs, sel, d_aa1.as<int32_t>(), P->identity, b0, best_arr, 0u, 1, (big_pass ? kA16BigSlot : a16_slot) - 96, dc + C_WIDE);
             }
             LAUNCH_CHECK();
             return PGX_OK;
@@ -3053,7 +3062,9 @@ static int cluster_greedy_impl(pgx_ctx *ctx, const uint8_t *d_residues, const ui
             }
             LAUNCH_CHECK();
             filter_walk_words += window_words * (both ? 2 : 1) / shard_count;
+            older_reps = true;
             int rc = evaluate_round();
+            older_reps = false;
             if (rc) return rc;
         }
         // append list[*lo, *hi) to the index as round `epoch_idx` (the bit map of touched codes is the round's)
