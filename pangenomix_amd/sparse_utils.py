@@ -53,7 +53,10 @@ def write_npz_parallel(path, members, chunk=1 << 20):
             arr = np.ascontiguousarray(arr)                   # (never for a 0-d array, which it would make 1-d)
         head = io.BytesIO()
         np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(arr))
-        body = arr.tobytes() if arr.ndim == 0 or arr.nbytes < chunk else memoryview(arr.reshape(-1)).cast('B')
+        try:
+            body = arr.tobytes() if arr.ndim == 0 or arr.nbytes < chunk else memoryview(arr.reshape(-1)).cast('B')
+        except (ValueError, TypeError):       # (a dtype the buffer protocol does not export, e.g. 'U': one copy)
+            body = arr.tobytes()
         raw = [head.getvalue() + bytes(body)] if len(body) < chunk else None
         if raw is None:     # the header travels with the first piece
             raw = [head.getvalue() + bytes(body[:chunk])] + [body[o:o + chunk] for o in range(chunk, len(body), chunk)]
