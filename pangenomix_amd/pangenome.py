@@ -437,7 +437,7 @@ class _Beside(object):
 
 
 def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, cluster_type, cdhit_args,
-                     fastasort_path, cluster_fn=None):
+                     fastasort_path, cluster_fn=None, after_tables=None):
     """consolidate_seqs -> cluster_with_cdhit -> rename_genes_and_alleles -> build_genetic_feature_tables
     with the file work in libpgx's multi-threaded host code (csrc/ingest.cpp) and the tables from
     arrays instead of per-record dictionaries: the same files, byte for byte, and the same LSDFs as the
@@ -445,7 +445,8 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
     Returns None when the fast path does not apply -- inputs the reference's line-by-line semantics
     treat specially (see pgx.h), duplicate genome names, an external fastasort, a multi-process group:
     the caller then runs the step-by-step functions. `cluster_fn(residues, offsets, params)` replaces the
-    GPU clustering call in tests (the CPU oracle, or a reader of a given .clstr)."""
+    GPU clustering call in tests (the CPU oracle, or a reader of a given .clstr). `after_tables(tables)` is called once
+    the tables exist, while the text outputs may still be being written (the caller's .npz files go there)."""
     import sys
     import time
     from . import _native, cluster
@@ -495,9 +496,6 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
             fs.write_clustered(cl, mem, iden, strand, nucleotide, prefix, VARIANT_TYPES['allele'],
                                clstr_path=nr_fasta + '.cdhit.clstr', names_path=names_tsv, nr_out_path=nr_fasta + '.tmp')
             os.replace(nr_fasta + '.tmp', nr_fasta)
-        # (the three text files and the tables below need nothing of each other: the files are written meanwhile)
-        outputs_written = _Beside(write_outputs)
-        beside.append(outputs_written)
         unclustered = np.flatnonzero(cl < 0)
         if unclustered.size:
             for h in fs.headers(fs.rep_of_group[unclustered]):
@@ -514,6 +512,10 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
         t = fs.feature_coo(cl, mem, file_order, genome_of_file)
         allele_groups = t['allele_groups']
         lap('tables: coordinates')
+        # (the three text files and the rest of the tables need nothing of each other: the files are written meanwhile;
+        # started behind the coordinates, which use all cores themselves)
+        outputs_written = _Beside(write_outputs)
+        beside.append(outputs_written)
         print('Sorting clusters...')
         c_sorted = cl[allele_groups]
         new_gene = np.ones(c_sorted.size, dtype=bool)
@@ -550,6 +552,8 @@ def _native_pipeline(genome_paths, nr_fasta, shared, missing, names_tsv, name, c
             except _native.PgxError as exc:       # (the tables are complete without it)
                 print('Note: no device-resident bitmap (%s)' % exc)
             lap('device-resident bitmap')
+        if after_tables is not None:
+            after_tables(out)
         outputs_written.wait()
         lap('.clstr, names, nr FASTA (the rest)')
         return out
@@ -616,10 +620,14 @@ def build_cds_pangenome(genome_faa_paths, output_dir, name='Test',
     nr_faa = _p(output_dir, name, '_nr.faa')
     shared = _p(output_dir, name, '_redundant_headers.tsv')
     missing = _p(output_dir, name, '_missing_headers.txt')
+    allele_npz = _p(output_dir, name, '_strain_by_allele') + '.npz'
+    gene_npz = _p(output_dir, name, '_strain_by_gene') + '.npz'
     fast = _native_pipeline(genome_faa_paths, nr_faa, shared, missing, _p(output_dir, name, '_allele_names.tsv'),
-                            name, 'cds', cdhit_args, fastasort_path) if output_format == 'lsdf' else None
+                            name, 'cds', cdhit_args, fastasort_path,
+                            after_tables=lambda t: _save_both(t[0], allele_npz, t[1], gene_npz)) \
+        if output_format == 'lsdf' else None
     if fast is not None:
-        df_alleles, df_genes = fast
+        return fast                 # (the tables were saved beside the last of the text outputs)
     else:
         consolidate_seqs(genome_faa_paths, nr_faa, shared, missing)
 
