@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU box (development aid): smoke(), `bench.py --gpus 2` on a one-GPU box (must fail loudly), and cfg-4 through RCCL at
+# world size 1 with both exchanges (torch.distributed's all-gather, the library's own ncclAllGather).
 set -o pipefail
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final_smoke.log 2>&1 || { tail -20 gpurun_out/final_smoke.log; exit 1; }

@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU box (development aid): the call without work counters against the call with them -- its parity tests, then both
+# timed on cfg-3s in one process, then the per-kernel table of the call without counters.
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_gpu_cluster.py -x -q -m gpu -k "without_counters" > gpurun_out/lean_tests.log 2>&1; rc=$?

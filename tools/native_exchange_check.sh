@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU box (development aid): the record-sharded tests, then cfg-3s through RCCL at world size 1 with both exchanges and
+# unsharded, for comparison.
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 500 python -m pytest tests/test_gpu_cluster_sharded.py -x -q -m "gpu and not slow" > gpurun_out/nat_tests.log 2>&1; rc=$?
