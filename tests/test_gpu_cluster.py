@@ -637,3 +637,34 @@ def test_without_counters_cfg3s_clusters_the_same(gpu_ctx):
     res, off, _ = synth.protein_set('cfg-3s').nr_arrays()
     p = params()
     assert_same_outputs(gpu_ctx.cluster_greedy(res, off, p, want_stats=False), gpu_ctx.cluster_greedy(res, off, p))
+
+
+def test_pairs_beyond_the_aligners_largest_slot(gpu_ctx):
+    """Pairs of two long sequences: up to 4,000 residues together they fit the 16-lane aligner's 4 KB slots, up to
+    8,096 the second pass with 8 KB slots (a window whose longest query exceeds 2,000 residues launches it), beyond
+    that the general one-pair-per-wave aligner -- and a short query against a much longer, older representative takes
+    the general aligner from any window. Families at each of these sizes, real members and near misses, against the
+    oracle (clusters, identities, counters)."""
+    rng = np.random.default_rng(77)
+    seqs = []
+    for length, n_members in ((1900, 4), (2050, 5), (2600, 5), (3900, 4), (4100, 4), (5200, 3)):
+        base = rand_seq(rng, length)
+        seqs.append(base)
+        for m in range(n_members):
+            frac = (0.05, 0.12, 0.19, 0.24, 0.30)[m % 5]                 # around the 0.8 threshold
+            member = mutate(rng, base, int(frac * length))
+            seqs.append(member[:length - int(rng.integers(0, length // 10))])
+        seqs.append(base[:400])                                          # a fragment: short query, long representative
+        seqs.append(mutate(rng, base[200:900], 60))
+    seqs += [rand_seq(rng, int(n)) for n in rng.integers(60, 900, 40)]
+    order = rng.permutation(len(seqs))
+    res, off = pack([seqs[i] for i in order])
+    for window in (0, 64):
+        p = params()
+        p.batch_size = window
+        got = gpu_ctx.cluster_greedy(res, off, p)
+        assert_same(got, oracle.cluster_greedy(res, off, p))
+        lean = gpu_ctx.cluster_greedy(res, off, p, want_stats=False)
+        for i in range(4):
+            np.testing.assert_array_equal(lean[i], got[i])
+    assert got[5]['aligned_pairs'] > 30
