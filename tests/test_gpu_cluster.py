@@ -668,3 +668,24 @@ def test_pairs_beyond_the_aligners_largest_slot(gpu_ctx):
         for i in range(4):
             np.testing.assert_array_equal(lean[i], got[i])
     assert got[5]['aligned_pairs'] > 30
+
+
+def test_word_list_kernels_at_their_class_boundaries(gpu_ctx):
+    """The word lists come from four kernels by word count (<= 512 and <= 1023: one wave per sequence with code and
+    count in one 32-bit slot; <= 2048: a workgroup per sequence; beyond: sorted). Sequences with exactly 511 .. 514,
+    1022 .. 1025 and 2047 .. 2050 words, and low-complexity ones whose single word reaches a count of 512, 1023 and
+    1024 -- the largest a ten-bit count holds and the first that must not take that path -- each with a near copy
+    that has to find it."""
+    rng = np.random.default_rng(5)
+    seqs = []
+    for words in (511, 512, 513, 514, 1022, 1023, 1024, 1025, 2047, 2048, 2049, 2050):
+        s = rand_seq(rng, words + 4)
+        seqs += [s, mutate(rng, s, max(3, words // 12))]
+    for words in (512, 1023, 1024):
+        seqs += ['A' * (words + 4), 'A' * (words + 2) + 'C' + 'A', 'AC' * ((words + 4) // 2)]
+    order = rng.permutation(len(seqs))
+    res, off = pack([seqs[i] for i in order])
+    p = params()
+    got = gpu_ctx.cluster_greedy(res, off, p)
+    assert_same(got, oracle.cluster_greedy(res, off, p))
+    assert got[4] < len(seqs)                       # the near copies joined
